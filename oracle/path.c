@@ -1,0 +1,418 @@
+/*
+ * oracle/path.c — TEST INFRASTRUCTURE ONLY (see hydia_oracle.h).
+ *
+ * The HyDia (approach 5) roles and the comparator, following the reference's orchestration:
+ *   DiagonalEnroller   /root/reference/src/enroller/enroller_diag.cpp:12-166
+ *   DiagonalReceiver   /root/reference/src/receiver/receiver_diag.cpp:13-26
+ *   HersReceiver::decrypt{Membership,Index}  /root/reference/src/receiver/receiver_hers.cpp:26-54
+ *   DiagonalSender     /root/reference/src/sender/sender_diag.cpp:12-94
+ *   OpenFHEWrapper::chebyshevCompare  /root/reference/src/openFHE_wrapper.cpp:143-185
+ *   VectorUtils::plaintextNormalize   /root/reference/src/vector_utils.cpp:32-51
+ */
+#include <math.h>
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "hydia_oracle.h"
+
+/* include/config.h:9,14,30 */
+#define MATCH_THRESHOLD 0.44
+#define COMP_DEPTH 10
+
+/* ------------------------------------------------------------------ comparator: plaintext side */
+/* EvalChebyshevCoefficients as called from EvalChebyshevFunction (openFHE_wrapper.cpp:173-174):
+ * interpolation of f(x) = (x >= delta ? 1 : -1) at the degree+1 Chebyshev nodes of [-1,1]. The series is
+ * sum_j c_j T_j(x) with c_0 already halved. */
+void hyo_chebyshev_step_coeffs(double delta, int degree, double *coeffs) {
+    int n = degree + 1;
+    double *f = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) {
+        double x = cos(M_PI * (i + 0.5) / n);
+        f[i] = (x >= delta) ? 1.0 : -1.0;
+    }
+    for (int j = 0; j < n; j++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += f[i] * cos(M_PI * j * (i + 0.5) / n);
+        coeffs[j] = s * 2.0 / n;
+    }
+    coeffs[0] *= 0.5;
+    free(f);
+}
+/* F4_COEFS, openFHE_wrapper.cpp:158-169 (Cheon et al. 2019/1234) */
+static const double F4[10] = {0.0, 315.0 / 128.0, 0.0, -420.0 / 128.0, 0.0, 378.0 / 128.0, 0.0, -180.0 / 128.0, 0.0, 35.0 / 128.0};
+
+/* the function chebyshevCompare approximates, evaluated in plain doubles (Clenshaw + Horner) */
+double hyo_compare_plain(double x, double delta, int degree) {
+    double *c = (double *)malloc(sizeof(double) * (degree + 1));
+    hyo_chebyshev_step_coeffs(delta, degree, c);
+    double b1 = 0, b2 = 0;
+    for (int j = degree; j >= 1; j--) {
+        double t = 2 * x * b1 - b2 + c[j];
+        b2 = b1;
+        b1 = t;
+    }
+    double y = x * b1 - b2 + c[0];
+    free(c);
+    double r = 0;
+    for (int i = 9; i >= 0; i--) r = r * y + F4[i];
+    return r + 1.0;
+}
+
+/* ------------------------------------------------------------------ comparator: encrypted side */
+typedef struct {
+    const hy_params *p;
+    const hy_keys *k;
+    hy_ct *T[9];   /* T[1..8] */
+    hy_ct *G[16];  /* G[i] = T_{8*2^i}, G[0] aliases T[8] */
+    int ng;
+} cheb_ctx;
+
+/* 2*a*b - c (c may be NULL meaning the constant 1): one ct x ct product, doubled before the rescale */
+static hy_ct *cheb_step(const hy_params *p, const hy_keys *k, const hy_ct *a, const hy_ct *b, const hy_ct *c) {
+    int nl = a->nl < b->nl ? a->nl : b->nl;
+    hy_ct *x = hyo_ct_clone(p, a), *y = hyo_ct_clone(p, b);
+    hyo_drop_to(p, x, nl);
+    hyo_drop_to(p, y, nl);
+    hy_ct *o = hyo_mult_norelin(p, x, y);
+    hyo_ct_free(x);
+    hyo_ct_free(y);
+    hyo_relin_inplace(p, k, o);
+    hyo_add_inplace(p, o, o); /* x2 */
+    hyo_rescale_inplace(p, o);
+    if (c) {
+        hy_ct *cc = hyo_ct_clone(p, c);
+        hyo_drop_to(p, cc, o->nl);
+        hyo_sub_inplace(p, o, cc);
+        hyo_ct_free(cc);
+    } else {
+        hyo_add_const(p, o, -1.0);
+    }
+    return o;
+}
+
+/* sum_{j<=deg} c_j T_j with deg <= 7: constants encoded so that the rescaled result has scale exactly Delta */
+static hy_ct *cheb_leaf(cheb_ctx *cx, const double *c, int deg) {
+    const hy_params *p = cx->p;
+    int nl = cx->T[1]->nl;
+    int any = 0;
+    for (int j = 1; j <= deg; j++)
+        if (c[j] != 0.0) {
+            any = 1;
+            if (cx->T[j]->nl < nl) nl = cx->T[j]->nl;
+        }
+    double S = p->delta * (double)p->q[nl - 1];
+    hy_ct *acc = NULL;
+    int last = any ? deg : 1; /* a pure constant is encoded as 0*T_1 + c_0 */
+    for (int j = 1; j <= last; j++) {
+        double cj = any ? c[j] : 0.0;
+        if (cj == 0.0 && any) continue;
+        hy_ct *t = hyo_ct_clone(p, cx->T[j]);
+        hyo_drop_to(p, t, nl);
+        hy_ct *m = hyo_mul_const(p, t, cj, S / t->scale);
+        m->scale = S;
+        hyo_ct_free(t);
+        if (!acc)
+            acc = m;
+        else {
+            hyo_add_inplace(p, acc, m);
+            hyo_ct_free(m);
+        }
+    }
+    hyo_add_const(p, acc, c[0]);
+    hyo_rescale_inplace(p, acc);
+    return acc;
+}
+
+/* evaluates sum_{j<=deg} c_j T_j, deg < 2*g where g = 8*2^gi (or deg < 8 when gi < 0) */
+static hy_ct *cheb_node(cheb_ctx *cx, const double *c, int deg, int gi) {
+    const hy_params *p = cx->p;
+    while (deg > 0 && c[deg] == 0.0) deg--;
+    if (deg < 8) return cheb_leaf(cx, c, deg);
+    int g = 8 << gi;
+    if (deg < g) return cheb_node(cx, c, deg, gi - 1);
+    /* c = q * T_g + r using T_j = 2 T_{j-g} T_g - T_{2g-j}  (g < j < 2g) */
+    double *qc = (double *)calloc(g, sizeof(double)), *rc = (double *)calloc(g, sizeof(double));
+    for (int j = 0; j < g; j++) rc[j] = c[j];
+    qc[0] = c[g];
+    for (int j = g + 1; j <= deg; j++) {
+        qc[j - g] = 2.0 * c[j];
+        rc[2 * g - j] -= c[j];
+    }
+    hy_ct *Q = cheb_node(cx, qc, deg - g, gi - 1);
+    hy_ct *R = cheb_node(cx, rc, g - 1, gi - 1);
+    hy_ct *prod = hyo_mult(p, cx->k, Q, cx->G[gi]);
+    int nl = prod->nl < R->nl ? prod->nl : R->nl;
+    hyo_drop_to(p, prod, nl);
+    hyo_drop_to(p, R, nl);
+    hyo_add_inplace(p, prod, R);
+    hyo_ct_free(Q);
+    hyo_ct_free(R);
+    free(qc);
+    free(rc);
+    return prod;
+}
+
+/* EvalChebyshevFunction's evaluation half (openFHE_wrapper.cpp:174) on [-1,1]: a baby-step/giant-step
+ * (Paterson-Stockmeyer) evaluation in the Chebyshev basis with babies T_1..T_8 and giants T_16, T_32, ...
+ * Depth ceil(log2(degree+1)) (6 for degree 59). */
+hy_ct *hyo_eval_chebyshev63(const hy_params *p, const hy_keys *k, const hy_ct *x, const double *coeffs, int degree) {
+    cheb_ctx cx;
+    memset(&cx, 0, sizeof(cx));
+    cx.p = p;
+    cx.k = k;
+    cx.T[1] = hyo_ct_clone(p, x);
+    int top = degree < 8 ? degree : 8;
+    if (top >= 2) cx.T[2] = cheb_step(p, k, cx.T[1], cx.T[1], NULL);
+    if (top >= 3) cx.T[3] = cheb_step(p, k, cx.T[2], cx.T[1], cx.T[1]);
+    if (top >= 4) cx.T[4] = cheb_step(p, k, cx.T[2], cx.T[2], NULL);
+    if (top >= 5) cx.T[5] = cheb_step(p, k, cx.T[3], cx.T[2], cx.T[1]);
+    if (top >= 6) cx.T[6] = cheb_step(p, k, cx.T[3], cx.T[3], NULL);
+    if (top >= 7) cx.T[7] = cheb_step(p, k, cx.T[4], cx.T[3], cx.T[1]);
+    if (top >= 8) cx.T[8] = cheb_step(p, k, cx.T[4], cx.T[4], NULL);
+    int gi = -1;
+    if (degree >= 8) {
+        cx.G[0] = cx.T[8];
+        gi = 0;
+        while ((8 << (gi + 1)) <= degree) {
+            cx.G[gi + 1] = cheb_step(p, k, cx.G[gi], cx.G[gi], NULL);
+            gi++;
+        }
+    }
+    cx.ng = gi + 1;
+    hy_ct *r = cheb_node(&cx, coeffs, degree, gi);
+    for (int j = 1; j <= 8; j++) hyo_ct_free(cx.T[j]);
+    for (int i = 1; i < cx.ng; i++) hyo_ct_free(cx.G[i]);
+    return r;
+}
+
+/* EvalPoly(ct, F4_COEFS) (openFHE_wrapper.cpp:179) in depth 4:
+ * f4(y) = (c1 y + c3 y^3) + y^4 (c5 y + c7 y^3) + (c9 y) y^8 */
+hy_ct *hyo_eval_f4(const hy_params *p, const hy_keys *k, const hy_ct *y) {
+    hy_ct *y2 = hyo_mult(p, k, y, y);
+    hy_ct *y3 = hyo_mult(p, k, y2, y);
+    hy_ct *y4 = hyo_mult(p, k, y2, y2);
+    hy_ct *y8 = hyo_mult(p, k, y4, y4);
+    int nl = y3->nl;
+    double S = p->delta * (double)p->q[nl - 1];
+    hy_ct *yd = hyo_ct_clone(p, y);
+    hyo_drop_to(p, yd, nl);
+    hy_ct *u = hyo_mul_const(p, yd, F4[1], S / yd->scale);
+    hy_ct *t = hyo_mul_const(p, y3, F4[3], S / y3->scale);
+    u->scale = t->scale = S;
+    hyo_add_inplace(p, u, t);
+    hyo_ct_free(t);
+    hyo_rescale_inplace(p, u);
+    hy_ct *v = hyo_mul_const(p, yd, F4[5], S / yd->scale);
+    t = hyo_mul_const(p, y3, F4[7], S / y3->scale);
+    v->scale = t->scale = S;
+    hyo_add_inplace(p, v, t);
+    hyo_ct_free(t);
+    hyo_rescale_inplace(p, v);
+    hyo_ct_free(yd);
+    double S0 = p->delta * (double)p->q[y->nl - 1];
+    hy_ct *w = hyo_mul_const(p, y, F4[9], S0 / y->scale);
+    w->scale = S0;
+    hyo_rescale_inplace(p, w);
+    hy_ct *a = hyo_mult(p, k, v, y4);
+    hy_ct *b = hyo_mult(p, k, w, y8);
+    int fl = a->nl < b->nl ? a->nl : b->nl;
+    if (u->nl < fl) fl = u->nl;
+    hyo_drop_to(p, a, fl);
+    hyo_drop_to(p, b, fl);
+    hyo_drop_to(p, u, fl);
+    hyo_add_inplace(p, a, b);
+    hyo_add_inplace(p, a, u);
+    hyo_ct_free(b);
+    hyo_ct_free(u);
+    hyo_ct_free(v);
+    hyo_ct_free(w);
+    hyo_ct_free(y2);
+    hyo_ct_free(y3);
+    hyo_ct_free(y4);
+    hyo_ct_free(y8);
+    return a;
+}
+
+/* OpenFHEWrapper::chebyshevCompare, openFHE_wrapper.cpp:143-185 */
+hy_ct *hyo_chebyshev_compare(const hy_params *p, const hy_keys *k, const hy_ct *x, double delta, int sign_depth) {
+    if (sign_depth < 7 || sign_depth > 15) { /* :146-149 — message, return the input unchanged */
+        fprintf(stderr, "Error: chebshevCompare requires a depth parameter between 7 and 15\n");
+        return hyo_ct_clone(p, x);
+    }
+    static const int DEPTH_TO_DEGREE[12] = {-1, -1, -1, 5, 13, 27, 59, 119, 247, 495, 1007, 2031}; /* :153-155 */
+    int degree = DEPTH_TO_DEGREE[sign_depth - 4];
+    double *c = (double *)malloc(sizeof(double) * (degree + 1));
+    hyo_chebyshev_step_coeffs(delta, degree, c);
+    hy_ct *y = hyo_eval_chebyshev63(p, k, x, c, degree);
+    free(c);
+    hy_ct *r = hyo_eval_f4(p, k, y);
+    hyo_ct_free(y);
+    hyo_add_const(p, r, 1.0); /* :182 */
+    return r;
+}
+
+/* ------------------------------------------------------------------ enroller */
+/* VectorUtils::plaintextNormalize, vector_utils.cpp:42-51 (zero vector passes through) */
+void hyo_normalize(double *x, int dim) {
+    double m = 0.0;
+    for (int i = 0; i < dim; i++) m += x[i] * x[i];
+    m = sqrt(m);
+    if (m != 0)
+        for (int i = 0; i < dim; i++) x[i] = x[i] / m;
+}
+/* concatenateRows' output count, enroller_diag.cpp:120-122 */
+size_t hyo_enroll_num_cts(const hy_params *p, size_t n) {
+    size_t dim = p->dim, per = p->slots / dim;
+    size_t nblk = (n + dim - 1) / dim;
+    return ((nblk + per - 1) / per) * dim;
+}
+/* slot vector of ciphertext t = g*dim + i: splitIntoSquareMatrices (:57-86, zero padded),
+ * preprocessToDiagonalForm (:99-115, diag[i][r] = M[r][(r+i) mod dim]), concatenateRows (:118-156,
+ * slots[j*dim + r] = diag_{block g*per + j}[i][r]) */
+void hyo_enroll_layout_row(const hy_params *p, const double *db, size_t n, size_t t, double *slots) {
+    size_t dim = p->dim, per = p->slots / dim;
+    size_t g = t / dim, i = t % dim;
+    for (size_t j = 0; j < per; j++) {
+        size_t blk = g * per + j;
+        for (size_t r = 0; r < dim; r++) {
+            size_t v = blk * dim + r;
+            slots[j * dim + r] = v < n ? db[v * dim + (r + i) % dim] : 0.0;
+        }
+    }
+}
+#define DB_NONCE_BASE (1ull << 36)
+/* DiagonalEnroller::serializeDB, enroller_diag.cpp:12-53 — normalises db IN PLACE like the reference;
+ * the ciphertexts stay in memory instead of serial/db_diagonal/index<t>.bin */
+hy_ct **hyo_enroll(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts) {
+    size_t dim = p->dim;
+#pragma omp parallel for
+    for (size_t v = 0; v < n; v++) hyo_normalize(db + v * dim, (int)dim);
+    size_t T = hyo_enroll_num_cts(p, n);
+    hy_ct **out = (hy_ct **)calloc(T, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+    for (size_t t = 0; t < T; t++) {
+        double *slots = (double *)malloc(sizeof(double) * p->slots);
+        hyo_enroll_layout_row(p, db, n, t, slots);
+        out[t] = hyo_encrypt(p, k, slots, p->slots, seed, DB_NONCE_BASE + t);
+        free(slots);
+    }
+    *n_cts = T;
+    return out;
+}
+
+/* ------------------------------------------------------------------ receiver */
+/* DiagonalReceiver::encryptQuery, receiver_diag.cpp:13-26 */
+hy_ct *hyo_encrypt_query(const hy_params *p, const hy_keys *k, const double *query, const uint8_t seed[32], u64 nonce) {
+    int dim = p->dim;
+    double *qn = (double *)malloc(sizeof(double) * dim);
+    memcpy(qn, query, sizeof(double) * dim);
+    hyo_normalize(qn, dim);
+    double *batch = (double *)malloc(sizeof(double) * p->slots);
+    for (int i = 0; i < p->slots; i += dim) memcpy(batch + i, qn, sizeof(double) * dim);
+    hy_ct *ct = hyo_encrypt(p, k, batch, p->slots, seed, nonce);
+    free(qn);
+    free(batch);
+    return ct;
+}
+/* HersReceiver::decryptMembership, receiver_hers.cpp:26-35 */
+int hyo_decrypt_membership(const hy_params *p, const hy_keys *k, const hy_ct *c) {
+    double *v = (double *)malloc(sizeof(double) * p->slots);
+    hyo_decrypt(p, k, c, v);
+    int r = v[0] >= 1.0;
+    free(v);
+    return r;
+}
+/* HersReceiver::decryptIndex, receiver_hers.cpp:37-54 */
+size_t hyo_decrypt_index(const hy_params *p, const hy_keys *k, hy_ct **cts, size_t n_cts, size_t *out, size_t cap) {
+    double *v = (double *)malloc(sizeof(double) * p->slots);
+    size_t cnt = 0;
+    for (size_t i = 0; i < n_cts; i++) {
+        hyo_decrypt(p, k, cts[i], v);
+        for (size_t j = 0; j < (size_t)p->slots; j++)
+            if (v[j] >= 1.0) {
+                if (cnt < cap) out[cnt] = j + i * p->slots;
+                cnt++;
+            }
+    }
+    free(v);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ sender */
+/* loop A, sender_diag.cpp:20-26: rot[0] = q, rot[i] = EvalFastRotation(q, i, 2N, precomp) */
+hy_ct **hyo_rotate_query(const hy_params *p, const hy_keys *k, const hy_ct *q) {
+    int dim = p->dim, N = p->N;
+    hy_ct **rot = (hy_ct **)calloc(dim, sizeof(hy_ct *));
+    rot[0] = hyo_ct_clone(p, q);
+    u64 *dig = hyo_hoist_precompute(p, q->d + (size_t)q->nl * N, q->nl);
+#pragma omp parallel for schedule(dynamic)
+    for (int i = 1; i < dim; i++) {
+        const u64 *evk = hyo_keys_rot(k, i);
+        rot[i] = evk ? hyo_rotate_hoisted(p, q, dig, evk, i) : NULL;
+        if (!evk) fprintf(stderr, "hydia oracle: missing rotation key %d\n", i);
+    }
+    free(dig);
+    return rot;
+}
+/* computeSimilarityMatrix + computeSimilarityThread, sender_diag.cpp:66-94: dim products without
+ * relinearisation, summed, ONE relinearise and ONE rescale */
+hy_ct *hyo_similarity_block(const hy_params *p, const hy_keys *k, hy_ct **rot, hy_ct **db_block) {
+    int dim = p->dim;
+    hy_ct **score = (hy_ct **)calloc(dim, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < dim; i++) score[i] = hyo_mult_norelin(p, rot[i], db_block[i]);
+    for (int i = 1; i < dim; i++) {
+        hyo_add_inplace(p, score[0], score[i]);
+        hyo_ct_free(score[i]);
+    }
+    hy_ct *acc = score[0];
+    free(score);
+    hyo_relin_inplace(p, k, acc);
+    hyo_rescale_inplace(p, acc);
+    return acc;
+}
+/* DiagonalSender::computeSimilarity, sender_diag.cpp:12-33 */
+hy_ct **hyo_compute_similarity(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out) {
+    size_t G = (n + p->slots - 1) / p->slots; /* :16 */
+    hy_ct **rot = hyo_rotate_query(p, k, q);
+    hy_ct **sim = (hy_ct **)calloc(G, sizeof(hy_ct *));
+    for (size_t m = 0; m < G; m++) sim[m] = hyo_similarity_block(p, k, rot, db + m * p->dim);
+    hyo_ct_array_free(rot, p->dim);
+    *n_out = G;
+    return sim;
+}
+/* DiagonalSender::indexScenario, sender_diag.cpp:52-63 */
+hy_ct **hyo_index_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out) {
+    hy_ct **score = hyo_compute_similarity(p, k, q, db, n, n_out);
+#pragma omp parallel for
+    for (size_t i = 0; i < *n_out; i++) {
+        hy_ct *c = hyo_chebyshev_compare(p, k, score[i], MATCH_THRESHOLD, COMP_DEPTH);
+        hyo_ct_free(score[i]);
+        score[i] = c;
+    }
+    return score;
+}
+/* DiagonalSender::membershipScenario, sender_diag.cpp:35-50: EvalAddManyInPlace then EvalSum over batchSize */
+hy_ct *hyo_membership_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n) {
+    size_t G;
+    hy_ct **score = hyo_index_scenario(p, k, q, db, n, &G);
+    hy_ct *m = score[0];
+    for (size_t i = 1; i < G; i++) {
+        hyo_add_inplace(p, m, score[i]);
+        hyo_ct_free(score[i]);
+    }
+    free(score);
+    for (int r = 1; r < p->slots; r <<= 1) {
+        hy_ct *t = hyo_rotate(p, k, m, r);
+        hyo_add_inplace(p, m, t);
+        hyo_ct_free(t);
+    }
+    return m;
+}
+
+hy_ct *hyo_ct_at(hy_ct **arr, size_t i) { return arr[i]; }
+void hyo_ct_array_free(hy_ct **arr, size_t n) {
+    for (size_t i = 0; i < n; i++) hyo_ct_free(arr[i]);
+    free(arr);
+}

@@ -1,0 +1,110 @@
+"""CPU oracle: the HyDia roles on a reduced ring, against plaintext cosine (the reference's own check,
+src/main_accuracy.cpp:354-364, tolerance 1e-4) and the >= 1.0 decision rule (src/receiver/receiver_hers.cpp:30,47)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+TOL = 1e-4  # src/main_accuracy.cpp:359-360
+
+
+def synth_db(rng, n, dim, matches):
+    """Distribution of tools/gen_dataset.sh: random rows in [-99,99], matching rows in {1,2,3}, query all ones."""
+    db = rng.integers(-99, 100, size=(n, dim)).astype(np.float64)
+    for i in matches:
+        db[i] = rng.integers(1, 4, size=dim)
+    return db
+
+
+def cosine(db, q):
+    nrm = np.linalg.norm(db, axis=1, keepdims=True)
+    nrm[nrm == 0] = 1.0
+    return (db / nrm) @ (q / np.linalg.norm(q))
+
+
+def test_enroll_layout_is_the_generalised_diagonal_packing(small_params):
+    """enroller_diag.cpp:99-156: slot j*dim + r of ciphertext g*dim + i holds M_{g*per+j}[r][(r+i) mod dim]."""
+    P = small_params
+    rng = np.random.default_rng(0)
+    n, dim, per = 1100, P.dim, P.slots // P.dim
+    db = rng.normal(size=(n, dim))
+    T = P.L.hyo_enroll_num_cts(P.h, n)
+    assert T == -(-(-(-n // dim)) // per) * dim == 2 * dim
+    slots = np.zeros(P.slots)
+    for t in (0, 1, dim - 1, dim, 2 * dim - 1):
+        P.L.hyo_enroll_layout_row(P.h, db.ctypes.data, n, t, slots.ctypes.data)
+        g, i = divmod(t, dim)
+        for j in (0, 1, per - 1):
+            for r in (0, 5, dim - 1):
+                v = (g * per + j) * dim + r
+                want = db[v, (r + i) % dim] if v < n else 0.0
+                assert slots[j * dim + r] == want
+
+
+def test_normalize_matches_reference_semantics(small_params):
+    P = small_params
+    x = np.arange(1.0, P.dim + 1)
+    y = x.copy()
+    P.L.hyo_normalize(y.ctypes.data, P.dim)
+    assert np.allclose(y, x / np.linalg.norm(x), rtol=0, atol=1e-15)
+    z = np.zeros(P.dim)
+    P.L.hyo_normalize(z.ctypes.data, P.dim)  # vector_utils.cpp:45: zero vector passes through
+    assert not z.any()
+
+
+@pytest.mark.parametrize("n,matches", [(1500, [0, 700, 1499]), (64, [63]), (1, [0]), (1024, []), (1025, [1024])])
+def test_hydia_path_small_ring(small_params, small_keys, n, matches):
+    P, Or = small_params, O.Oracle(small_params, small_keys)
+    rng = np.random.default_rng(n)
+    db = synth_db(rng, n, P.dim, matches)
+    query = np.ones(P.dim)
+    cos = cosine(db, query)
+    dbc = Or.enroll(db.copy(), 99)
+    assert len(dbc) == P.L.hyo_enroll_num_cts(P.h, n)
+    q = Or.encrypt_query(query, 5, 1)
+    sim = Or.compute_similarity(q, dbc, n)
+    G = -(-n // P.slots)
+    assert len(sim) == G and sim[0].nl == P.nQ - 1 and sim[0].npoly == 2
+    scores = np.concatenate([Or.decrypt(sim[i]) for i in range(G)])
+    assert np.abs(scores[:n] - cos).max() < TOL
+    assert n == len(scores) or np.abs(scores[n:]).max() < TOL  # padded rows score 0
+    idx = Or.index_scenario(q, dbc, n)
+    assert idx[0].nl == 1
+    assert Or.decrypt_index(idx) == sorted(matches)
+    mem = Or.membership_scenario(q, dbc, n)
+    assert Or.decrypt_membership(mem) == (len(matches) > 0)
+
+
+def test_zero_vector_row_and_enroll_normalises_in_place(small_params, small_keys):
+    P, Or = small_params, O.Oracle(small_params, small_keys)
+    rng = np.random.default_rng(1)
+    db = synth_db(rng, 100, P.dim, [3])
+    db[10] = 0.0
+    cos = cosine(db, np.ones(P.dim))
+    arr = db.copy()
+    dbc = Or.enroll(arr, 1)
+    assert np.allclose(np.linalg.norm(np.delete(arr, 10, axis=0), axis=1), 1.0)  # enroller_diag.cpp:32-35 mutates
+    assert not arr[10].any()
+    sim = Or.compute_similarity(Or.encrypt_query(np.ones(P.dim), 5, 1), dbc, 100)
+    s = Or.decrypt(sim[0])
+    assert np.abs(s[:100] - cos).max() < TOL and abs(s[10]) < TOL
+
+
+def test_compare_guard_and_plain_curve(small_params, small_keys):
+    P, Or = small_params, O.Oracle(small_params, small_keys)
+    x = np.linspace(-1, 1, P.slots)
+    ct = Or.encrypt(x, 3, 1)
+    P.L.hyo_drop_to(P.h, ct.h, P.nQ - 1)
+    out = Or.decrypt(Or.chebyshev_compare(ct, 0.44, 10))
+    ref = np.array([P.L.hyo_compare_plain(float(v), 0.44, 59) for v in x])
+    assert np.abs(out - ref).max() < TOL
+    # decisions: everything below the transition band -> < 1, above -> >= 1
+    assert (out[x < 0.43] < 1.0).all() and (out[x > 0.47] >= 1.0).all()
+    # openFHE_wrapper.cpp:146-149: depth outside 7..15 -> message, input returned unchanged
+    same = Or.chebyshev_compare(ct, 0.44, 6)
+    assert same.nl == ct.nl and np.array_equal(same.data(), ct.data())
+    # lower depths of the reference's DEPTH_TO_DEGREE table
+    for depth, degree in ((7, 5), (8, 13), (9, 27)):
+        o = Or.decrypt(Or.chebyshev_compare(ct, 0.44, depth))
+        r = np.array([P.L.hyo_compare_plain(float(v), 0.44, degree) for v in x])
+        assert np.abs(o - r).max() < TOL
