@@ -1,0 +1,492 @@
+// image_matching_amd/csrc/capi.cpp — the extern "C" boundary of libhydia.so (include/hydia.h).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/hydia.h"
+#include "client.h"
+#include "hydia_core.h"
+
+using namespace hydia;
+
+struct hydia_ctx {
+    Context cx;
+    hydia_ctx(const Params &p, int dev) : cx(p, dev) {}
+};
+struct hydia_ct {
+    Ct c;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define API_BEGIN try {
+#define API_END                                                          \
+    }                                                                    \
+    catch (const std::runtime_error &e) {                                \
+        std::string m = e.what();                                        \
+        int code = m.find("hip") != std::string::npos ? HYDIA_ERR_DEVICE \
+                   : m.find("not loaded") != std::string::npos || m.find("no database") != std::string::npos ||  \
+                     m.find("must be a fresh") != std::string::npos ? HYDIA_ERR_STATE : HYDIA_ERR_ARG;            \
+        return fail(code, m);                                            \
+    }                                                                    \
+    catch (const std::exception &e) { return fail(HYDIA_ERR_INTERNAL, e.what()); }
+#define REQUIRE(cond, msg) \
+    if (!(cond)) return fail(HYDIA_ERR_ARG, msg)
+
+static Params to_params(const hydia_params *p) {
+    Params r;
+    r.logN = (int)p->log_n;
+    r.mult_depth = (int)p->mult_depth;
+    r.scale_bits = (int)p->scale_bits;
+    r.first_bits = (int)p->first_mod_bits;
+    r.dnum = (int)p->dnum;
+    r.dim = (int)p->vector_dim;
+    return r;
+}
+static void fill_info(const HostParams &h, hydia_info *o) {
+    o->log_n = h.prm.logN; o->n = h.N; o->slots = h.slots; o->n_q = h.nQ; o->n_p = h.nP; o->dnum = h.prm.dnum;
+    o->alpha = h.alpha; o->vector_dim = h.prm.dim; o->delta = h.delta;
+}
+static hydia_ct *wrap(Ct &&c) {
+    hydia_ct *h = new hydia_ct;
+    h->c = std::move(c);
+    return h;
+}
+
+extern "C" {
+
+const char *hydia_last_error(void) { return g_err.c_str(); }
+const char *hydia_version(void) { return "hydia-mi355x 0.1 (gfx950)"; }
+
+void hydia_default_params(hydia_params *o) {
+    o->log_n = 15;
+    o->mult_depth = (uint32_t)hydia_compute_required_depth(5);
+    o->scale_bits = 45;
+    o->first_mod_bits = 60;
+    o->dnum = 3;
+    o->vector_dim = 512;
+}
+/* src/openFHE_wrapper.cpp:6-44 with COMP_DEPTH 10, ALPHA_DEPTH 2 (include/config.h:14,18) */
+size_t hydia_compute_required_depth(size_t approach) {
+    const size_t COMP_DEPTH = 10, ALPHA_DEPTH = 2;
+    switch (approach) {
+        case 1: return 1 + 2 + COMP_DEPTH;
+        case 2: return 1 + 2 + ALPHA_DEPTH + 3 + COMP_DEPTH;
+        case 3: return 1 + 1 + COMP_DEPTH;
+        case 4: return 1 + COMP_DEPTH;
+        case 5: return 1 + COMP_DEPTH;
+        default: return 0;
+    }
+}
+int hydia_params_describe(const hydia_params *p, hydia_info *info, uint64_t *moduli, uint64_t *roots) {
+    API_BEGIN
+    REQUIRE(p, "null params");
+    HostParams h(to_params(p));
+    if (info) fill_info(h, info);
+    for (int m = 0; m < h.nT; m++) {
+        if (moduli) moduli[m] = h.q[m];
+        if (roots) roots[m] = h.psi[m];
+    }
+    return HYDIA_OK;
+    API_END
+}
+int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out) {
+    API_BEGIN
+    REQUIRE(p && out, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
+    REQUIRE(device >= 0 && device < ndev, "bad device index");
+    *out = new hydia_ctx(to_params(p), device);
+    return HYDIA_OK;
+    API_END
+}
+void hydia_ctx_destroy(hydia_ctx *ctx) { delete ctx; }
+int hydia_get_info(const hydia_ctx *ctx, hydia_info *out) {
+    REQUIRE(ctx && out, "null argument");
+    fill_info(ctx->cx, out);
+    return HYDIA_OK;
+}
+int hydia_get_moduli(const hydia_ctx *ctx, uint64_t *moduli, uint64_t *roots) {
+    REQUIRE(ctx, "null ctx");
+    for (int m = 0; m < ctx->cx.nT; m++) {
+        if (moduli) moduli[m] = ctx->cx.q[m];
+        if (roots) roots[m] = ctx->cx.psi[m];
+    }
+    return HYDIA_OK;
+}
+int hydia_sync(hydia_ctx *ctx) {
+    API_BEGIN
+    REQUIRE(ctx, "null ctx");
+    ctx->cx.sync();
+    return HYDIA_OK;
+    API_END
+}
+int hydia_memory_stats(hydia_ctx *ctx, uint64_t *live, uint64_t *cached, uint64_t *peak) {
+    REQUIRE(ctx, "null ctx");
+    if (live) *live = ctx->cx.pool.bytes_live;
+    if (cached) *cached = ctx->cx.pool.bytes_cached;
+    if (peak) *peak = ctx->cx.pool.peak;
+    return HYDIA_OK;
+}
+
+// ------------------------------------------------------------------ keys
+int hydia_keygen(hydia_ctx *ctx, const uint8_t seed[32]) {
+    API_BEGIN
+    REQUIRE(ctx && seed, "null argument");
+    client_keygen(ctx->cx, seed);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_import_eval_key(hydia_ctx *ctx, int rot, const uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data && rot >= 0 && rot < ctx->cx.slots, "bad argument");
+    ctx->cx.load_eval_key(rot, (const u64 *)data);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_export_eval_key(hydia_ctx *ctx, int rot, uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    Context &cx = ctx->cx;
+    const u64 *src = nullptr;
+    if (rot == 0) src = cx.relin_key.d;
+    else if (cx.rot_keys.count(rot)) src = cx.rot_keys[rot].d;
+    if (!src) return fail(HYDIA_ERR_STATE, "hydia: evaluation key not loaded");
+    cx.sync();
+    HIP_CHECK(hipMemcpy(data, src, (size_t)cx.prm.dnum * 2 * cx.nT * cx.N * sizeof(u64), hipMemcpyDeviceToHost));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_fill_eval_keys_random(hydia_ctx *ctx, uint64_t seed) {
+    API_BEGIN
+    REQUIRE(ctx, "null ctx");
+    Context &cx = ctx->cx;
+    std::vector<int> rots;
+    rots.push_back(0);
+    for (int i = 1; i < cx.prm.dim; i++) rots.push_back(i);
+    for (int i = cx.prm.dim; i < cx.slots; i <<= 1) rots.push_back(i);
+    for (int r : rots) {
+        u64 *d = cx.eval_key_storage(r);
+        // [dnum][2][nT][N]: limb slot index modulo nT selects the modulus
+        hk::fill_uniform_hash(cx.stream, cx.d_mod, cx.N, d, (size_t)cx.prm.dnum * 2 * cx.nT, cx.nT, seed + 7919ull * r);
+    }
+    cx.sync();
+    return HYDIA_OK;
+    API_END
+}
+int hydia_has_eval_key(hydia_ctx *ctx, int rot) {
+    if (!ctx) return 0;
+    if (rot == 0) return ctx->cx.relin_key.d != nullptr;
+    auto it = ctx->cx.rot_keys.find(rot);
+    return it != ctx->cx.rot_keys.end() && it->second.d != nullptr;
+}
+static int import_buf(Context &cx, u64 **slot, const uint64_t *data, size_t elems) {
+    if (!*slot) HIP_CHECK(hipMalloc((void **)slot, elems * sizeof(u64)));
+    HIP_CHECK(hipMemcpy(*slot, data, elems * sizeof(u64), hipMemcpyHostToDevice));
+    return HYDIA_OK;
+}
+int hydia_import_public_key(hydia_ctx *ctx, const uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    return import_buf(ctx->cx, &ctx->cx.d_pk, data, (size_t)2 * ctx->cx.nQ * ctx->cx.N);
+    API_END
+}
+int hydia_import_secret_key(hydia_ctx *ctx, const uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    return import_buf(ctx->cx, &ctx->cx.d_sk, data, (size_t)ctx->cx.nT * ctx->cx.N);
+    API_END
+}
+int hydia_export_public_key(hydia_ctx *ctx, uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    if (!ctx->cx.d_pk) return fail(HYDIA_ERR_STATE, "hydia: public key not loaded");
+    ctx->cx.sync();
+    HIP_CHECK(hipMemcpy(data, ctx->cx.d_pk, (size_t)2 * ctx->cx.nQ * ctx->cx.N * sizeof(u64), hipMemcpyDeviceToHost));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_export_secret_key(hydia_ctx *ctx, uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    if (!ctx->cx.d_sk) return fail(HYDIA_ERR_STATE, "hydia: secret key not loaded");
+    ctx->cx.sync();
+    HIP_CHECK(hipMemcpy(data, ctx->cx.d_sk, (size_t)ctx->cx.nT * ctx->cx.N * sizeof(u64), hipMemcpyDeviceToHost));
+    return HYDIA_OK;
+    API_END
+}
+
+// ------------------------------------------------------------------ ciphertext handles
+int hydia_ct_import(hydia_ctx *ctx, const uint64_t *data, uint32_t count, uint32_t n_polys, uint32_t n_limbs, double scale,
+                    hydia_ct **out) {
+    API_BEGIN
+    REQUIRE(ctx && data && out, "null argument");
+    REQUIRE(count >= 1 && (n_polys == 2 || n_polys == 3) && n_limbs >= 1 && (int)n_limbs <= ctx->cx.nQ, "bad ciphertext shape");
+    Ct c(&ctx->cx, (int)count, (int)n_polys, (int)n_limbs, scale);
+    ctx->cx.sync();
+    HIP_CHECK(hipMemcpy(c.d, data, c.bytes(), hipMemcpyHostToDevice));
+    *out = wrap(std::move(c));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_ct_export(hydia_ctx *ctx, const hydia_ct *ct, uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && ct && data, "null argument");
+    ctx->cx.sync();
+    HIP_CHECK(hipMemcpy(data, ct->c.d, ct->c.bytes(), hipMemcpyDeviceToHost));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_ct_shape(const hydia_ct *ct, uint32_t *count, uint32_t *n_polys, uint32_t *n_limbs, double *scale) {
+    REQUIRE(ct, "null ct");
+    if (count) *count = ct->c.X;
+    if (n_polys) *n_polys = ct->c.npoly;
+    if (n_limbs) *n_limbs = ct->c.nl;
+    if (scale) *scale = ct->c.scale;
+    return HYDIA_OK;
+}
+int hydia_ct_device_ptr(const hydia_ct *ct, void **ptr, size_t *bytes) {
+    REQUIRE(ct && ptr, "null argument");
+    *ptr = ct->c.d;
+    if (bytes) *bytes = ct->c.bytes();
+    return HYDIA_OK;
+}
+int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
+                         double scale, hydia_ct **out) {
+    API_BEGIN
+    REQUIRE(ctx && dev_ptr && out && count >= 1, "bad argument");
+    Ct c(&ctx->cx, (int)count, (int)n_polys, (int)n_limbs, scale);
+    ctx->cx.sync();
+    HIP_CHECK(hipMemcpy(c.d, dev_ptr, c.bytes(), hipMemcpyDeviceToDevice));
+    *out = wrap(std::move(c));
+    return HYDIA_OK;
+    API_END
+}
+void hydia_ct_free(hydia_ct *ct) { delete ct; }
+
+// ------------------------------------------------------------------ receiver
+int hydia_encrypt_query(hydia_ctx *ctx, const double *query, const uint8_t seed[32], uint64_t nonce, hydia_ct **out) {
+    API_BEGIN
+    REQUIRE(ctx && query && seed && out, "null argument");
+    *out = wrap(client_encrypt_query(ctx->cx, query, seed, nonce));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_encrypt(hydia_ctx *ctx, const double *slots, uint32_t count, const uint8_t seed[32], uint64_t nonce0,
+                  hydia_ct **out) {
+    API_BEGIN
+    REQUIRE(ctx && slots && seed && out && count >= 1, "bad argument");
+    *out = wrap(client_encrypt(ctx->cx, slots, (int)count, seed, nonce0));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_decrypt(hydia_ctx *ctx, const hydia_ct *ct, double *out) {
+    API_BEGIN
+    REQUIRE(ctx && ct && out, "null argument");
+    client_decrypt(ctx->cx, ct->c, out);
+    return HYDIA_OK;
+    API_END
+}
+/* receiver_hers.cpp:26-35 */
+int hydia_decrypt_membership(hydia_ctx *ctx, const hydia_ct *ct, int *result) {
+    API_BEGIN
+    REQUIRE(ctx && ct && result, "null argument");
+    std::vector<double> v((size_t)ct->c.X * ctx->cx.slots);
+    client_decrypt(ctx->cx, ct->c, v.data());
+    *result = v[0] >= 1.0 ? 1 : 0;
+    return HYDIA_OK;
+    API_END
+}
+/* receiver_hers.cpp:37-54 */
+int hydia_decrypt_index(hydia_ctx *ctx, const hydia_ct *cts, size_t *out, size_t cap, size_t *n_out) {
+    API_BEGIN
+    REQUIRE(ctx && cts && n_out, "null argument");
+    const size_t S = ctx->cx.slots;
+    std::vector<double> v((size_t)cts->c.X * S);
+    client_decrypt(ctx->cx, cts->c, v.data());
+    size_t cnt = 0;
+    for (size_t i = 0; i < (size_t)cts->c.X; i++)
+        for (size_t j = 0; j < S; j++)
+            if (v[i * S + j] >= 1.0) {
+                if (out && cnt < cap) out[cnt] = j + i * S;
+                cnt++;
+            }
+    *n_out = cnt;
+    return HYDIA_OK;
+    API_END
+}
+
+// ------------------------------------------------------------------ enroller / database
+size_t hydia_db_num_cts(const hydia_ctx *ctx, size_t n) {
+    if (!ctx) return 0;
+    const size_t dim = ctx->cx.prm.dim, per = ctx->cx.slots / dim;
+    const size_t nblk = (n + dim - 1) / dim;
+    return ((nblk + per - 1) / per) * dim;
+}
+static void db_alloc(Context &cx, size_t n_vectors, size_t cts) {
+    const size_t bytes = cts * 2 * cx.nQ * cx.N * sizeof(u64);
+    if (cx.d_db && cx.db_cts != cts) {
+        cx.sync();
+        HIP_CHECK(hipFree(cx.d_db));
+        cx.d_db = nullptr;
+    }
+    if (!cx.d_db && bytes) HIP_CHECK(hipMalloc((void **)&cx.d_db, bytes));
+    cx.db_cts = cts;
+    cx.db_vectors = n_vectors;
+}
+int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors) {
+    API_BEGIN
+    REQUIRE(ctx && n_vectors >= 1, "bad argument");
+    db_alloc(ctx->cx, n_vectors, hydia_db_num_cts(ctx, n_vectors));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    Context &cx = ctx->cx;
+    if (!cx.d_db) return fail(HYDIA_ERR_STATE, "hydia: no database resident (call hydia_db_alloc)");
+    REQUIRE(t < cx.db_cts, "ciphertext index out of range");
+    const size_t e = (size_t)2 * cx.nQ * cx.N;
+    cx.sync();
+    HIP_CHECK(hipMemcpy(cx.d_db + t * e, data, e * sizeof(u64), hipMemcpyHostToDevice));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data) {
+    API_BEGIN
+    REQUIRE(ctx && data, "null argument");
+    Context &cx = ctx->cx;
+    if (!cx.d_db) return fail(HYDIA_ERR_STATE, "hydia: no database resident");
+    REQUIRE(t < cx.db_cts, "ciphertext index out of range");
+    const size_t e = (size_t)2 * cx.nQ * cx.N;
+    cx.sync();
+    HIP_CHECK(hipMemcpy(data, cx.d_db + t * e, e * sizeof(u64), hipMemcpyDeviceToHost));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
+    API_BEGIN
+    REQUIRE(ctx && n_vectors >= 1, "bad argument");
+    Context &cx = ctx->cx;
+    const size_t cts = hydia_db_num_cts(ctx, n_vectors);
+    db_alloc(cx, n_vectors, cts);
+    hk::fill_uniform_hash(cx.stream, cx.d_mod, cx.N, cx.d_db, cts * 2 * cx.nQ, cx.nQ, seed);
+    cx.sync();
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
+    API_BEGIN
+    REQUIRE(ctx && db && seed && n >= 1, "bad argument");
+    Context &cx = ctx->cx;
+    db_alloc(cx, n, hydia_db_num_cts(ctx, n));
+    client_enroll(cx, db, n, seed);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_t *bytes) {
+    REQUIRE(ctx, "null ctx");
+    if (n_vectors) *n_vectors = ctx->cx.db_vectors;
+    if (n_cts) *n_cts = ctx->cx.db_cts;
+    if (bytes) *bytes = ctx->cx.db_cts * 2 * ctx->cx.nQ * ctx->cx.N * sizeof(u64);
+    return HYDIA_OK;
+}
+
+// ------------------------------------------------------------------ sender
+#define SENDER_CALL(expr)                                 \
+    API_BEGIN                                             \
+    REQUIRE(ctx && query && out, "null argument");        \
+    *out = wrap(expr);                                    \
+    return HYDIA_OK;                                      \
+    API_END
+int hydia_rotate_query(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.rotate_query(query->c)) }
+int hydia_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.similarity(query->c)) }
+int hydia_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.index_scenario(query->c)) }
+int hydia_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.membership_scenario(query->c)) }
+int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *query, double delta, size_t sign_depth, hydia_ct **out) {
+    SENDER_CALL(ctx->cx.chebyshev_compare(query->c, delta, (int)sign_depth))
+}
+int hydia_sum_and_evalsum(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.sum_and_evalsum(query->c)) }
+
+// ------------------------------------------------------------------ primitives
+int hydia_ntt(hydia_ctx *ctx, uint64_t *data, uint32_t count, uint32_t m, int inverse) {
+    API_BEGIN
+    REQUIRE(ctx && data && count >= 1 && (int)m < ctx->cx.nT, "bad argument");
+    Context &cx = ctx->cx;
+    const size_t bytes = (size_t)count * cx.N * sizeof(u64);
+    u64 *d = cx.pool.get(bytes);
+    cx.sync();
+    HIP_CHECK(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
+    LimbSel s = cx.sel_range((int)m, (int)m + 1);
+    if (inverse) cx.ntt_inv(d, d, cx.N, cx.N, (int)count, s, cx.scale_ninv(s));
+    else cx.ntt_fwd(d, cx.N, (int)count, s);
+    cx.sync();
+    HIP_CHECK(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost));
+    cx.pool.put(d);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_eval_rotate(hydia_ctx *ctx, const hydia_ct *query, int rot, hydia_ct **out) { SENDER_CALL(ctx->cx.rotate(query->c, rot)) }
+int hydia_eval_mult(hydia_ctx *ctx, const hydia_ct *query, const hydia_ct *b, hydia_ct **out) {
+    if (!b) return fail(HYDIA_ERR_ARG, "null argument");
+    SENDER_CALL(ctx->cx.mult(query->c, b->c))
+}
+int hydia_eval_mult_no_relin(hydia_ctx *ctx, const hydia_ct *query, const hydia_ct *b, hydia_ct **out) {
+    if (!b) return fail(HYDIA_ERR_ARG, "null argument");
+    SENDER_CALL(ctx->cx.mult_norelin(query->c, b->c))
+}
+int hydia_relinearize(hydia_ctx *ctx, hydia_ct *ct) {
+    API_BEGIN
+    REQUIRE(ctx && ct, "null argument");
+    ctx->cx.relinearize(ct->c);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_rescale(hydia_ctx *ctx, hydia_ct *ct) {
+    API_BEGIN
+    REQUIRE(ctx && ct, "null argument");
+    ctx->cx.rescale(ct->c);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_eval_add(hydia_ctx *ctx, hydia_ct *a, const hydia_ct *b) {
+    API_BEGIN
+    REQUIRE(ctx && a && b, "null argument");
+    ctx->cx.add_inplace(a->c, b->c);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs) {
+    API_BEGIN
+    REQUIRE(ctx && ct && n_limbs >= 1, "bad argument");
+    ctx->cx.drop_to(ct->c, (int)n_limbs);
+    return HYDIA_OK;
+    API_END
+}
+
+// ------------------------------------------------------------------ measurement
+int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64_t *launches) {
+    API_BEGIN
+    REQUIRE(ctx && name, "null argument");
+    ctx->cx.timer_collect();
+    auto it = ctx->cx.timers.find(name);
+    if (total_ms) *total_ms = it == ctx->cx.timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == ctx->cx.timers.end() ? 0 : (uint64_t)it->second.launches;
+    return HYDIA_OK;
+    API_END
+}
+int hydia_kernel_time_reset(hydia_ctx *ctx) {
+    API_BEGIN
+    REQUIRE(ctx, "null ctx");
+    ctx->cx.timer_collect();
+    ctx->cx.timers.clear();
+    return HYDIA_OK;
+    API_END
+}
+
+}  // extern "C"

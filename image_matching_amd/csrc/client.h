@@ -1,0 +1,12 @@
+// image_matching_amd/csrc/client.h — receiver / enroller / key-generation engines (GPU): sampling, canonical-embedding
+// encode/decode, public-key encryption, decryption, on-GPU enrolment into the HBM-resident diagonal layout.
+#pragma once
+#include "hydia_core.h"
+
+namespace hydia {
+void client_keygen(Context &cx, const uint8_t seed[32]);
+Ct client_encrypt(Context &cx, const double *slots, int count, const uint8_t seed[32], uint64_t nonce0);
+Ct client_encrypt_query(Context &cx, const double *query, const uint8_t seed[32], uint64_t nonce);
+void client_decrypt(Context &cx, const Ct &ct, double *out);
+void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]);
+}  // namespace hydia

@@ -1,0 +1,385 @@
+// image_matching_amd/csrc/context.cpp — CKKS-RNS context for the HyDia path on MI355X.
+//
+// Parameter derivation replaces GenCryptoContext(HEStd_128_classic, depth 11, ScalingModSize 45, FIXEDMANUAL) of
+// /root/reference/src/main.cpp:169-179: N = 2^15, Q = one 60-bit + eleven ~45-bit NTT primes, hybrid key switching
+// with dnum = 3 (alpha = 4 limbs per digit) and four 60-bit special primes P.  The prime/root selection rule is this
+// framework's own deterministic specification (DESIGN.md §"RNS parameters"); tests check it against the oracle.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "hydia_core.h"
+
+namespace hydia {
+
+// ------------------------------------------------------------------ host number theory
+u64 mulmod_u64(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+u64 powmod_u64(u64 a, u64 e, u64 q) {
+    u64 r = 1 % q;
+    a %= q;
+    for (; e; e >>= 1) {
+        if (e & 1) r = mulmod_u64(r, a, q);
+        a = mulmod_u64(a, a, q);
+    }
+    return r;
+}
+u64 invmod_u64(u64 a, u64 q) { return powmod_u64(a % q, q - 2, q); }
+
+static bool miller_rabin(u64 n) {
+    if (n < 2) return false;
+    for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull})
+        if (n % p == 0) return n == p;
+    u64 d = n - 1;
+    int r = 0;
+    while (!(d & 1)) d >>= 1, r++;
+    for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        u64 x = powmod_u64(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool witness = true;
+        for (int i = 1; i < r && witness; i++) {
+            x = mulmod_u64(x, x, n);
+            if (x == n - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
+// NTT primes are = 1 mod 2N.  next_ntt_prime: smallest such prime >= lo; prev_ntt_prime: largest such prime < hi.
+static u64 next_ntt_prime(u64 lo, u64 M) {
+    u64 c = lo + (M + 1 - lo % M) % M;
+    while (!miller_rabin(c)) c += M;
+    return c;
+}
+static u64 prev_ntt_prime(u64 hi, u64 M) {
+    u64 c = hi - 1;
+    c -= (c % M + M - 1) % M;
+    while (!miller_rabin(c)) c -= M;
+    return c;
+}
+static u64 find_psi(u64 q, u64 M) {
+    for (u64 x = 2;; x++) {
+        u64 r = powmod_u64(x, (q - 1) / M, q);
+        if (powmod_u64(r, M / 2, q) == q - 1) return r;  // order exactly 2N
+    }
+}
+static unsigned bitrev(unsigned x, int bits) {
+    unsigned r = 0;
+    for (int i = 0; i < bits; i++, x >>= 1) r = (r << 1) | (x & 1);
+    return r;
+}
+static u64 shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+
+static ModC make_modc(u64 q, int N) {
+    ModC m{};
+    m.q = q;
+    int k = 64 - __builtin_clzll(q);
+    m.ks = k - 2;
+    m.mu = (u64)((((u128)1) << (k + 62)) / q);
+    m.r64 = (u64)((((u128)1) << 64) / q);
+    u128 hi = (((u128)1) << 64) / q, rem = (((u128)1) << 64) % q;
+    u128 full = (hi << 64) + ((rem << 64) / q);
+    m.r0 = (u64)full;
+    m.r1 = (u64)(full >> 64);
+    m.ninv = invmod_u64((u64)N, q);
+    m.ninv_sh = shoup(m.ninv, q);
+    return m;
+}
+
+u64 double_to_mod(double v, u64 q) {
+    bool neg = v < 0;
+    double a = std::fabs(v);
+    u64 r;
+    if (a < 9223372036854775808.0) {
+        r = (u64)std::llrint(a) % q;
+    } else {
+        int e;
+        double m = std::frexp(a, &e);
+        u64 mant = (u64)std::ldexp(m, 53);
+        r = mulmod_u64(mant % q, powmod_u64(2, (u64)(e - 53), q), q);
+    }
+    return neg ? (r ? q - r : 0) : r;
+}
+
+// ------------------------------------------------------------------ pool
+Pool::~Pool() { trim(); }
+u64 *Pool::get(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_.lower_bound(bytes);
+    u64 *p;
+    if (it != free_.end() && it->first <= bytes + bytes / 4 + 4096) {
+        p = it->second;
+        bytes_cached -= it->first;
+        bytes = it->first;
+        free_.erase(it);
+    } else {
+        hipError_t e = hipMalloc((void **)&p, bytes);
+        if (e != hipSuccess) {
+            trim();
+            HIP_CHECK(hipMalloc((void **)&p, bytes));
+        }
+    }
+    size_[p] = bytes;
+    bytes_live += bytes;
+    peak = std::max(peak, bytes_live + bytes_cached);
+    return p;
+}
+void Pool::put(u64 *p) {
+    if (!p) return;
+    auto it = size_.find(p);
+    if (it == size_.end()) return;
+    free_.emplace(it->second, p);
+    bytes_live -= it->second;
+    bytes_cached += it->second;
+    size_.erase(it);
+}
+void Pool::trim() {
+    for (auto &kv : free_) (void)hipFree(kv.second);
+    free_.clear();
+    bytes_cached = 0;
+}
+
+// ------------------------------------------------------------------ Ct
+Ct::Ct(Context *c, int X_, int npoly_, int nl_, double scale_) : ctx(c), X(X_), npoly(npoly_), nl(nl_), scale(scale_) {
+    d = c->pool.get(bytes());
+}
+Ct &Ct::operator=(Ct &&o) noexcept {
+    if (this != &o) {
+        if (d && !view && ctx) ctx->pool.put(d);
+        ctx = o.ctx; d = o.d; X = o.X; npoly = o.npoly; nl = o.nl; scale = o.scale; view = o.view;
+        o.d = nullptr;
+    }
+    return *this;
+}
+Ct::~Ct() {
+    if (d && !view && ctx) ctx->pool.put(d);
+}
+size_t Ct::ct_elems() const { return (size_t)npoly * nl * ctx->N; }
+
+// ------------------------------------------------------------------ context
+HostParams::HostParams(const Params &p) : prm(p) {
+    if (p.logN < 11 || p.logN > 16) throw std::runtime_error("hydia: log_n must be in [11,16]");
+    if (p.dnum < 1 || p.mult_depth < 1) throw std::runtime_error("hydia: bad dnum / depth");
+    N = 1 << p.logN;
+    slots = N / 2;
+    nQ = p.mult_depth + 1;
+    alpha = (nQ + p.dnum - 1) / p.dnum;
+    if (alpha > HY_MAX_DIGIT) throw std::runtime_error("hydia: digit too wide");
+    if (p.dim < 1 || (p.dim & (p.dim - 1)) || p.dim > slots) throw std::runtime_error("hydia: dim must be a power of two <= N/2");
+    delta = std::ldexp(1.0, p.scale_bits);
+    const u64 M = 2ull * N;
+
+    q.assign(nQ, 0);
+    // scaling primes, assigned from the last limb down, alternating above / below 2^scale_bits
+    u64 up = next_ntt_prime(1ull << p.scale_bits, M), dn = up;
+    for (int i = 0; i < nQ - 1; i++) {
+        int j = nQ - 1 - i;
+        if (i == 0) q[j] = up;
+        else if (i & 1) q[j] = dn = prev_ntt_prime(dn, M);
+        else q[j] = up = next_ntt_prime(up + 1, M);
+    }
+    u64 cur = prev_ntt_prime(1ull << p.first_bits, M);
+    if (p.first_bits == p.scale_bits)
+        while (std::find(q.begin() + 1, q.end(), cur) != q.end()) cur = prev_ntt_prime(cur, M);
+    q[0] = cur;
+    int digit_bits = 0;
+    for (int j = 0; j < alpha && j < nQ; j++) digit_bits += (j == 0 ? p.first_bits : p.scale_bits + 1);
+    nP = std::max(1, (digit_bits + 59) / 60);
+    nT = nQ + nP;
+    if (nT > HY_MAX_MODS) throw std::runtime_error("hydia: too many limbs");
+    u64 pc = (p.first_bits == 60) ? q[0] : (1ull << 60);
+    for (int k = 0; k < nP; k++) q.push_back(pc = prev_ntt_prime(pc, M));
+
+    psi.resize(nT);
+    mod.resize(nT);
+    for (int m = 0; m < nT; m++) {
+        psi[m] = find_psi(q[m], M);
+        mod[m] = make_modc(q[m], N);
+    }
+    P_mod_q.resize(nQ);
+    Pinv_mod_q.resize(nQ);
+    for (int j = 0; j < nQ; j++) {
+        u64 pr = 1;
+        for (int k = 0; k < nP; k++) pr = mulmod_u64(pr, q[nQ + k] % q[j], q[j]);
+        P_mod_q[j] = pr;
+        Pinv_mod_q[j] = invmod_u64(pr, q[j]);
+    }
+    Phat_inv.resize(nP);
+    Phat_mod_q.assign(nP, std::vector<u64>(nQ));
+    for (int k = 0; k < nP; k++) {
+        u64 pk = q[nQ + k], pr = 1;
+        for (int i = 0; i < nP; i++)
+            if (i != k) pr = mulmod_u64(pr, q[nQ + i] % pk, pk);
+        Phat_inv[k] = invmod_u64(pr, pk);
+        for (int j = 0; j < nQ; j++) {
+            u64 v = 1;
+            for (int i = 0; i < nP; i++)
+                if (i != k) v = mulmod_u64(v, q[nQ + i] % q[j], q[j]);
+            Phat_mod_q[k][j] = v;
+        }
+    }
+    ql_inv.assign(nQ, std::vector<u64>(nQ, 0));
+    for (int l = 0; l < nQ; l++)
+        for (int j = 0; j < l; j++) ql_inv[l][j] = invmod_u64(q[l] % q[j], q[j]);
+
+}
+
+void HostParams::twiddles(int m, std::vector<u64> &tw, std::vector<u64> &tws, std::vector<u64> &itw,
+                          std::vector<u64> &itws) const {
+    std::vector<u64> pw(N), ipw(N);
+    u64 ipsi = invmod_u64(psi[m], q[m]);
+    pw[0] = ipw[0] = 1;
+    for (int i = 1; i < N; i++) {
+        pw[i] = mulmod_u64(pw[i - 1], psi[m], q[m]);
+        ipw[i] = mulmod_u64(ipw[i - 1], ipsi, q[m]);
+    }
+    tw.resize(N); tws.resize(N); itw.resize(N); itws.resize(N);
+    for (int k = 0; k < N; k++) {
+        unsigned r = bitrev((unsigned)k, prm.logN);
+        tw[k] = pw[r];
+        tws[k] = shoup(pw[r], q[m]);
+        itw[k] = ipw[r];
+        itws[k] = shoup(ipw[r], q[m]);
+    }
+}
+
+Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
+    // ---- device side
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    size_t tb = (size_t)nT * N * sizeof(u64);
+    std::vector<u64> tw((size_t)nT * N), tws((size_t)nT * N), itw((size_t)nT * N), itws((size_t)nT * N);
+    for (int m = 0; m < nT; m++) {
+        std::vector<u64> a, b, c, d;
+        twiddles(m, a, b, c, d);
+        std::copy(a.begin(), a.end(), tw.begin() + (size_t)m * N);
+        std::copy(b.begin(), b.end(), tws.begin() + (size_t)m * N);
+        std::copy(c.begin(), c.end(), itw.begin() + (size_t)m * N);
+        std::copy(d.begin(), d.end(), itws.begin() + (size_t)m * N);
+    }
+    HIP_CHECK(hipMalloc((void **)&d_mod, sizeof(ModC) * nT));
+    HIP_CHECK(hipMalloc((void **)&d_tw, tb));
+    HIP_CHECK(hipMalloc((void **)&d_tw_sh, tb));
+    HIP_CHECK(hipMalloc((void **)&d_itw, tb));
+    HIP_CHECK(hipMalloc((void **)&d_itw_sh, tb));
+    HIP_CHECK(hipMemcpy(d_mod, mod.data(), sizeof(ModC) * nT, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_tw, tw.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_tw_sh, tws.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_itw, itw.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_itw_sh, itws.data(), tb, hipMemcpyHostToDevice));
+    tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod};
+    HIP_CHECK(hipMalloc((void **)&d_rotptrs, sizeof(u64 *) * (size_t)p.dim));
+    HIP_CHECK(hipMalloc((void **)&d_rotgalois, sizeof(unsigned) * (size_t)p.dim));
+
+}
+
+Context::~Context() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &kv : timers)
+        for (auto &ev : kv.second.pending) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    pool.trim();
+    rot_keys[0] = relin_key;
+    for (auto &kv : rot_keys)
+        for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
+            if (p) (void)hipFree(p);
+    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_rotptrs,
+                    (void *)d_rotgalois, (void *)d_sk, (void *)d_pk, (void *)d_db})
+        if (p) (void)hipFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+LimbSel Context::sel_q(int nl) const { return sel_range(0, nl); }
+LimbSel Context::sel_range(int lo, int hi) const {
+    LimbSel s{};
+    s.n = hi - lo;
+    for (int j = lo; j < hi; j++) s.mod[j - lo] = j;
+    return s;
+}
+LimbSel Context::sel_ext(int nl) const {
+    LimbSel s{};
+    s.n = nl + nP;
+    for (int j = 0; j < nl; j++) s.mod[j] = j;
+    for (int k = 0; k < nP; k++) s.mod[nl + k] = nQ + k;
+    return s;
+}
+ScaleSel Context::scale_ninv(const LimbSel &s) const {
+    ScaleSel r{};
+    for (int i = 0; i < s.n; i++) {
+        r.s[i] = mod[s.mod[i]].ninv;
+        r.s_sh[i] = mod[s.mod[i]].ninv_sh;
+    }
+    return r;
+}
+ScaleSel Context::scale_of(const LimbSel &s, const std::vector<u64> &v, bool times_ninv) const {
+    ScaleSel r{};
+    for (int i = 0; i < s.n; i++) {
+        u64 qq = q[s.mod[i]];
+        u64 val = v[i] % qq;
+        if (times_ninv) val = mulmod_u64(val, mod[s.mod[i]].ninv, qq);
+        r.s[i] = val;
+        r.s_sh[i] = shoup(val, qq);
+    }
+    return r;
+}
+u64 Context::galois_elt(int rot) const {
+    u64 M = 2ull * N, g = 1;
+    int r = ((rot % slots) + slots) % slots;
+    for (int i = 0; i < r; i++) g = (g * 5) % M;
+    return g;
+}
+
+// ------------------------------------------------------------------ evaluation keys
+u64 *Context::eval_key_storage(int rot) {
+    EvalKey &k = rot == 0 ? relin_key : rot_keys[rot];
+    if (!k.d) {
+        const size_t bytes = (size_t)prm.dnum * 2 * nT * N * sizeof(u64);
+        HIP_CHECK(hipMalloc((void **)&k.d, bytes));
+        HIP_CHECK(hipMalloc((void **)&k.d_cell, sizeof(u64 *)));
+        HIP_CHECK(hipMalloc((void **)&k.d_gal, sizeof(unsigned)));
+        const u64 *self = k.d;
+        unsigned g = rot == 0 ? 1u : (unsigned)galois_elt(rot);
+        HIP_CHECK(hipMemcpy((void *)k.d_cell, &self, sizeof(u64 *), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(k.d_gal, &g, sizeof(unsigned), hipMemcpyHostToDevice));
+        rotptrs_valid = false;
+    }
+    return k.d;
+}
+void Context::load_eval_key(int rot, const u64 *host) {
+    u64 *dst = eval_key_storage(rot);
+    sync();
+    HIP_CHECK(hipMemcpy(dst, host, (size_t)prm.dnum * 2 * nT * N * sizeof(u64), hipMemcpyHostToDevice));
+}
+
+// ------------------------------------------------------------------ kernel timers
+void Context::timer_begin(const char *name) {
+    if (!timing) return;
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, stream));
+    timers[name].pending.emplace_back(a, b);
+}
+void Context::timer_end(const char *name) {
+    if (!timing) return;
+    auto &t = timers[name];
+    HIP_CHECK(hipEventRecord(t.pending.back().second, stream));
+}
+void Context::timer_collect() {
+    for (auto &kv : timers) {
+        for (auto &ev : kv.second.pending) {
+            HIP_CHECK(hipEventSynchronize(ev.second));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+            kv.second.total_ms += ms;
+            kv.second.launches++;
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+}  // namespace hydia

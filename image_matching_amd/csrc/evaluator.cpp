@@ -1,0 +1,450 @@
+// image_matching_amd/csrc/evaluator.cpp — batched CKKS evaluator and the HyDia sender engine on MI355X.
+//
+// Mirrors, as batched HBM-resident operations on one HIP stream, the OpenFHE calls of the reference's hot path:
+//   DiagonalSender::computeSimilarity        /root/reference/src/sender/sender_diag.cpp:12-33   -> Context::similarity
+//   DiagonalSender::computeSimilarityMatrix  /root/reference/src/sender/sender_diag.cpp:66-83   -> tensor kernel + relinearize + rescale
+//   DiagonalSender::indexScenario / membershipScenario  sender_diag.cpp:35-63                    -> index_scenario / membership_scenario
+//   OpenFHEWrapper::chebyshevCompare         /root/reference/src/openFHE_wrapper.cpp:143-185     -> chebyshev_compare
+// Every operation works on a batch of X ciphertexts so the per-block tails (relinearise, rescale, comparator) of all
+// DB blocks resident on this GPU run as ONE launch sequence with X-times larger grids.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "hydia_core.h"
+
+namespace hydia {
+
+static u64 shoup_h(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+
+void Context::ntt_fwd(u64 *base, size_t outer, int X, const LimbSel &s) {
+    if (X <= 0 || s.n <= 0) return;
+    hk::ntt_forward(stream, tabs, prm.logN, base, base, outer, outer, X, s);
+}
+void Context::ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc) {
+    if (X <= 0 || s.n <= 0) return;
+    hk::ntt_inverse(stream, tabs, prm.logN, src, dst, so, dso, X, s, sc);
+}
+
+// ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
+// extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
+// NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.
+void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig) {
+    const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
+    const size_t dig_x = (size_t)nd * nE * N;
+    const LimbSel esel = sel_ext(nl);
+    u64 *y = pool.get((size_t)X * alpha * N * sizeof(u64));
+    for (int d = 0; d < nd; d++) {
+        const int lo = d * alpha, hi = std::min(lo + alpha, nl), sz = hi - lo;
+        const LimbSel dsel = sel_range(lo, hi);
+        std::vector<u64> inv(sz);
+        ConvTab tab{};
+        tab.ns = sz;
+        tab.nt = nE;
+        tab.skip_lo = lo;
+        tab.skip_hi = hi;
+        for (int s = 0; s < sz; s++) {
+            const u64 qj = q[lo + s];
+            u64 pr = 1;
+            for (int i = lo; i < hi; i++)
+                if (i != lo + s) pr = mulmod_u64(pr, q[i] % qj, qj);
+            inv[s] = invmod_u64(pr, qj);
+            for (int t = 0; t < nE; t++) {
+                const u64 qt = q[esel.mod[t]];
+                u64 f = 1;
+                for (int i = lo; i < hi; i++)
+                    if (i != lo + s) f = mulmod_u64(f, q[i] % qt, qt);
+                tab.f[s][t] = f;
+            }
+        }
+        ntt_inv(c + (size_t)lo * N, y, c_outer, (size_t)sz * N, X, dsel, scale_of(dsel, inv, true));
+        u64 *out = dig + (size_t)d * nE * N;
+        hk::base_convert(stream, d_mod, N, y, (size_t)sz * N, out, dig_x, X, tab, esel);
+        if (lo > 0) ntt_fwd(out, dig_x, X, sel_range(0, lo));
+        LimbSel rest{};
+        rest.n = nE - hi;
+        for (int t = hi; t < nE; t++) rest.mod[t - hi] = esel.mod[t];
+        ntt_fwd(out + (size_t)hi * N, dig_x, X, rest);
+        hk::copy_limbs(stream, N, c + (size_t)lo * N, out + (size_t)lo * N, c_outer, dig_x, X, sz);
+    }
+    pool.put(y);
+}
+
+// <digits, key> over Q_l u P, then ModDown by P; optionally adds `addend` and applies the evaluation-form
+// automorphism (EvalFastRotation's tail).  out: [X][2][nl][N].
+void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
+                       const u64 *addend, size_t add_x_stride, int add_polys, const unsigned *d_galois, int same_galois,
+                       u64 *out) {
+    const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
+    const LimbSel esel = sel_ext(nl);
+    u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
+    timer_begin("ks_inner_product");
+    hk::inner_product(stream, d_mod, N, dig, dig_x_stride, nd, d_keys, same_key, nT, acc, X, esel);
+    timer_end("ks_inner_product");
+    // P limbs -> coefficient form, pre-multiplied by (P/p_k)^{-1}
+    LimbSel psel = sel_range(nQ, nT);
+    u64 *y = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
+    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
+    ConvTab tab{};
+    tab.ns = nP;
+    tab.nt = nl;
+    tab.skip_lo = tab.skip_hi = 0;
+    for (int k = 0; k < nP; k++)
+        for (int j = 0; j < nl; j++) tab.f[k][j] = Phat_mod_q[k][j];
+    u64 *conv = pool.get((size_t)X * 2 * nl * N * sizeof(u64));
+    const LimbSel qsel = sel_q(nl);
+    hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
+    ntt_fwd(conv, (size_t)nl * N, X * 2, qsel);
+    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
+    hk::moddown_combine(stream, d_mod, prm.logN, acc, nE, conv, addend, add_x_stride, add_polys, out, X, nl,
+                        scale_of(qsel, pinv, false), d_galois, same_galois);
+    pool.put(conv);
+    pool.put(y);
+    pool.put(acc);
+}
+
+void Context::build_rotptrs() {
+    if (rotptrs_valid) return;
+    std::vector<const u64 *> ptrs(prm.dim, nullptr);
+    std::vector<unsigned> gal(prm.dim, 1u);
+    for (int i = 1; i < prm.dim; i++) {
+        auto it = rot_keys.find(i);
+        if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(i) + " not loaded");
+        ptrs[i] = it->second.d;
+        gal[i] = (unsigned)galois_elt(i);
+    }
+    HIP_CHECK(hipMemcpy((void *)d_rotptrs, ptrs.data(), sizeof(u64 *) * prm.dim, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_rotgalois, gal.data(), sizeof(unsigned) * prm.dim, hipMemcpyHostToDevice));
+    rotptrs_valid = true;
+}
+
+// RelinearizeInPlace (sender_diag.cpp:79)
+void Context::relinearize(Ct &c) {
+    if (c.npoly != 3) return;
+    if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
+    const int nl = c.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X;
+    u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
+    modup_digits(c.d + (size_t)2 * nl * N, (size_t)3 * nl * N, X, nl, dig);
+    Ct out(this, X, 2, nl, c.scale);
+    ks_apply(dig, (size_t)nd * nE * N, X, nl, relin_key.d_cell, 1, c.d, (size_t)3 * nl * N, 2, nullptr, 0, out.d);
+    pool.put(dig);
+    c = std::move(out);
+}
+// RescaleInPlace (sender_diag.cpp:80): divide by the last prime with rounding to nearest
+void Context::rescale(Ct &c) {
+    const int nl = c.nl, l = nl - 1, XP = c.X * c.npoly;
+    if (nl < 2) throw std::runtime_error("hydia: rescale with one limb left");
+    u64 *t = pool.get((size_t)XP * N * sizeof(u64));
+    const LimbSel last = sel_range(l, l + 1);
+    ntt_inv(c.d + (size_t)l * N, t, (size_t)nl * N, (size_t)N, XP, last, scale_ninv(last));
+    u64 *tmp = pool.get((size_t)XP * l * N * sizeof(u64));
+    hk::rescale_spread(stream, d_mod, N, t, tmp, XP, l);
+    const LimbSel qsel = sel_q(l);
+    ntt_fwd(tmp, (size_t)l * N, XP, qsel);
+    Ct out(this, c.X, c.npoly, l, c.scale / (double)q[l]);
+    std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
+    hk::rescale_combine(stream, d_mod, N, c.d, tmp, out.d, XP, l, scale_of(qsel, qi, false));
+    pool.put(tmp);
+    pool.put(t);
+    c = std::move(out);
+}
+Ct Context::clone(const Ct &a) {
+    Ct o(this, a.X, a.npoly, a.nl, a.scale);
+    HIP_CHECK(hipMemcpyAsync(o.d, a.d, a.bytes(), hipMemcpyDeviceToDevice, stream));
+    return o;
+}
+void Context::drop_to(Ct &a, int nl) {
+    if (nl >= a.nl) return;
+    Ct o(this, a.X, a.npoly, nl, a.scale);
+    hk::copy_limbs(stream, N, a.d, o.d, (size_t)a.nl * N, (size_t)nl * N, a.X * a.npoly, nl);
+    a = std::move(o);
+}
+static void check_same(const Ct &a, const Ct &b, const char *what) {
+    if (a.X != b.X || a.npoly != b.npoly || a.nl != b.nl)
+        throw std::runtime_error(std::string("hydia: shape mismatch in ") + what);
+}
+void Context::add_inplace(Ct &a, const Ct &b) {
+    check_same(a, b, "add");
+    hk::add(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl));
+}
+void Context::sub_inplace(Ct &a, const Ct &b) {
+    check_same(a, b, "sub");
+    hk::sub(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl));
+}
+// EvalAddInPlace(ct, double) (openFHE_wrapper.cpp:182)
+void Context::add_const(Ct &a, double c) {
+    const LimbSel s = sel_q(a.nl);
+    ScaleSel sc{};
+    for (int j = 0; j < a.nl; j++) sc.s[j] = double_to_mod(c * a.scale, q[j]);
+    hk::add_scalar(stream, d_mod, N, a.d, a.ct_elems(), a.X, s, sc);
+}
+Ct Context::mul_const(const Ct &a, double c, double const_scale) {
+    const LimbSel s = sel_q(a.nl);
+    ScaleSel sc{};
+    for (int j = 0; j < a.nl; j++) {
+        sc.s[j] = double_to_mod(c * const_scale, q[j]);
+        sc.s_sh[j] = shoup_h(sc.s[j], q[j]);
+    }
+    Ct o(this, a.X, a.npoly, a.nl, a.scale * const_scale);
+    hk::mul_scalar(stream, d_mod, N, a.d, o.d, a.X * a.npoly, s, sc);
+    return o;
+}
+// EvalMultNoRelin (sender_diag.cpp:93)
+Ct Context::mult_norelin(const Ct &a, const Ct &b) {
+    if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
+    Ct o(this, a.X, 3, a.nl, a.scale * b.scale);
+    hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl);
+    return o;
+}
+Ct Context::mult(const Ct &a, const Ct &b) {
+    const int nl = std::min(a.nl, b.nl);
+    Ct x, y;
+    const Ct *pa = &a, *pb = &b;
+    if (a.nl != nl) {
+        x = clone(a);
+        drop_to(x, nl);
+        pa = &x;
+    }
+    if (b.nl != nl) {
+        y = clone(b);
+        drop_to(y, nl);
+        pb = &y;
+    }
+    Ct o = mult_norelin(*pa, *pb);
+    relinearize(o);
+    rescale(o);
+    return o;
+}
+// EvalRotate on every ciphertext of the batch (EvalSum's step, sender_diag.cpp:47)
+Ct Context::rotate(const Ct &a, int rot) {
+    auto it = rot_keys.find(rot);
+    if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(rot) + " not loaded");
+    const int nl = a.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = a.X;
+    u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
+    modup_digits(a.d + (size_t)nl * N, (size_t)2 * nl * N, X, nl, dig);
+    Ct out(this, X, 2, nl, a.scale);
+    ks_apply(dig, (size_t)nd * nE * N, X, nl, it->second.d_cell, 1, a.d, (size_t)2 * nl * N, 1, it->second.d_gal, 1, out.d);
+    pool.put(dig);
+    return out;
+}
+
+// ------------------------------------------------------------------ HyDia sender
+// loop A (sender_diag.cpp:20-26): ONE ModUp of the query's c1, then dim-1 hoisted rotations as one batched
+// inner-product + ModDown + automorphism sequence.  Output: rot[0] = q, rot[i] = Rot_i(q).
+Ct Context::rotate_query(const Ct &qc) {
+    if (qc.X != 1 || qc.npoly != 2) throw std::runtime_error("hydia: query must be one 2-component ciphertext");
+    build_rotptrs();
+    const int nl = qc.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, dim = prm.dim;
+    u64 *dig = pool.get((size_t)nd * nE * N * sizeof(u64));
+    modup_digits(qc.d + (size_t)nl * N, 0, 1, nl, dig);
+    Ct rot(this, dim, 2, nl, qc.scale);
+    HIP_CHECK(hipMemcpyAsync(rot.d, qc.d, qc.bytes(), hipMemcpyDeviceToDevice, stream));
+    if (dim > 1)
+        ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, 1, d_rotgalois + 1, 0, rot.d + rot.ct_elems());
+    pool.put(dig);
+    return rot;
+}
+// computeSimilarity (sender_diag.cpp:12-33): all G blocks of the resident DB in one tensor-accumulate launch
+Ct Context::similarity(const Ct &qc) {
+    if (!d_db || db_cts == 0) throw std::runtime_error("hydia: no database resident");
+    if (qc.nl != nQ) throw std::runtime_error("hydia: query must be a fresh (level 0) ciphertext");
+    const int dim = prm.dim;
+    const int G = (int)(db_cts / dim);
+    Ct rot = rotate_query(qc);
+    Ct acc(this, G, 3, nQ, qc.scale * delta);
+    timer_begin("hydia_tensor");
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ);
+    timer_end("hydia_tensor");
+    relinearize(acc);
+    rescale(acc);
+    return acc;
+}
+
+// ------------------------------------------------------------------ comparator
+namespace {
+struct Cheb {
+    Context *cx;
+    std::vector<Ct> T;  // T[1..8]
+    std::vector<Ct> G;  // G[i] = T_{8*2^i}; G[0] is a view of T[8]
+};
+// 2ab - c (c == nullptr: the constant 1)
+Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
+    const int nl = std::min(a.nl, b.nl);
+    Ct x = cx->clone(a), y;
+    cx->drop_to(x, nl);
+    const Ct *pb = &x;
+    if (&a != &b) {
+        y = cx->clone(b);
+        cx->drop_to(y, nl);
+        pb = &y;
+    }
+    Ct o = cx->mult_norelin(x, *pb);
+    cx->relinearize(o);
+    cx->add_inplace(o, o);
+    cx->rescale(o);
+    if (c) {
+        Ct cc = cx->clone(*c);
+        cx->drop_to(cc, o.nl);
+        cx->sub_inplace(o, cc);
+    } else {
+        cx->add_const(o, -1.0);
+    }
+    return o;
+}
+Ct cheb_leaf(Cheb &ch, const double *c, int deg) {
+    Context *cx = ch.cx;
+    int nl = ch.T[1].nl;
+    bool any = false;
+    for (int j = 1; j <= deg; j++)
+        if (c[j] != 0.0) {
+            any = true;
+            nl = std::min(nl, ch.T[j].nl);
+        }
+    const double S = cx->delta * (double)cx->q[nl - 1];
+    Ct acc;
+    const int last = any ? deg : 1;
+    for (int j = 1; j <= last; j++) {
+        const double cj = any ? c[j] : 0.0;
+        if (cj == 0.0 && any) continue;
+        Ct t = cx->clone(ch.T[j]);
+        cx->drop_to(t, nl);
+        Ct m = cx->mul_const(t, cj, S / t.scale);
+        m.scale = S;
+        if (!acc.d) acc = std::move(m);
+        else cx->add_inplace(acc, m);
+    }
+    cx->add_const(acc, c[0]);
+    cx->rescale(acc);
+    return acc;
+}
+Ct cheb_node(Cheb &ch, const double *c, int deg, int gi) {
+    Context *cx = ch.cx;
+    while (deg > 0 && c[deg] == 0.0) deg--;
+    if (deg < 8) return cheb_leaf(ch, c, deg);
+    const int g = 8 << gi;
+    if (deg < g) return cheb_node(ch, c, deg, gi - 1);
+    std::vector<double> qc(g, 0.0), rc(g, 0.0);
+    for (int j = 0; j < g; j++) rc[j] = c[j];
+    qc[0] = c[g];
+    for (int j = g + 1; j <= deg; j++) {
+        qc[j - g] = 2.0 * c[j];
+        rc[2 * g - j] -= c[j];
+    }
+    Ct Q = cheb_node(ch, qc.data(), deg - g, gi - 1);
+    Ct R = cheb_node(ch, rc.data(), g - 1, gi - 1);
+    Ct prod = cx->mult(Q, ch.G[gi]);
+    const int nl = std::min(prod.nl, R.nl);
+    cx->drop_to(prod, nl);
+    cx->drop_to(R, nl);
+    cx->add_inplace(prod, R);
+    return prod;
+}
+// interpolation of step-at-delta at the degree+1 Chebyshev nodes (what EvalChebyshevFunction derives)
+std::vector<double> step_coeffs(double delta, int degree) {
+    const int n = degree + 1;
+    std::vector<double> f(n), c(n);
+    for (int i = 0; i < n; i++) f[i] = (std::cos(M_PI * (i + 0.5) / n) >= delta) ? 1.0 : -1.0;
+    for (int j = 0; j < n; j++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += f[i] * std::cos(M_PI * j * (i + 0.5) / n);
+        c[j] = s * 2.0 / n;
+    }
+    c[0] *= 0.5;
+    return c;
+}
+const double F4[10] = {0.0, 315.0 / 128.0, 0.0, -420.0 / 128.0, 0.0, 378.0 / 128.0, 0.0, -180.0 / 128.0, 0.0, 35.0 / 128.0};
+}  // namespace
+
+// OpenFHEWrapper::chebyshevCompare (openFHE_wrapper.cpp:143-185) on a batch of score ciphertexts.
+Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
+    if (sign_depth < 7 || sign_depth > 15) {  // :146-149
+        fprintf(stderr, "Error: chebshevCompare requires a depth parameter between 7 and 15\n");
+        return clone(x);
+    }
+    static const int DEPTH_TO_DEGREE[12] = {-1, -1, -1, 5, 13, 27, 59, 119, 247, 495, 1007, 2031};  // :153-155
+    const int degree = DEPTH_TO_DEGREE[sign_depth - 4];
+    std::vector<double> c = step_coeffs(dlt, degree);
+    Cheb ch;
+    ch.cx = this;
+    ch.T.resize(9);
+    ch.T[1] = clone(x);
+    const int top = std::min(degree, 8);
+    if (top >= 2) ch.T[2] = cheb_step(this, ch.T[1], ch.T[1], nullptr);
+    if (top >= 3) ch.T[3] = cheb_step(this, ch.T[2], ch.T[1], &ch.T[1]);
+    if (top >= 4) ch.T[4] = cheb_step(this, ch.T[2], ch.T[2], nullptr);
+    if (top >= 5) ch.T[5] = cheb_step(this, ch.T[3], ch.T[2], &ch.T[1]);
+    if (top >= 6) ch.T[6] = cheb_step(this, ch.T[3], ch.T[3], nullptr);
+    if (top >= 7) ch.T[7] = cheb_step(this, ch.T[4], ch.T[3], &ch.T[1]);
+    if (top >= 8) ch.T[8] = cheb_step(this, ch.T[4], ch.T[4], nullptr);
+    int gi = -1;
+    if (degree >= 8) {
+        ch.G.emplace_back();
+        Ct &g0 = ch.G.back();
+        g0.ctx = this; g0.d = ch.T[8].d; g0.X = ch.T[8].X; g0.npoly = 2; g0.nl = ch.T[8].nl; g0.scale = ch.T[8].scale;
+        g0.view = true;
+        gi = 0;
+        while ((8 << (gi + 1)) <= degree) {
+            Ct nx = cheb_step(this, ch.G[gi], ch.G[gi], nullptr);
+            ch.G.push_back(std::move(nx));
+            gi++;
+        }
+    }
+    Ct y = cheb_node(ch, c.data(), degree, gi);
+    ch.G.clear();
+    ch.T.clear();
+    // f4 in depth 4: (c1 y + c3 y^3) + y^4 (c5 y + c7 y^3) + (c9 y) y^8   (openFHE_wrapper.cpp:158-169, :179)
+    Ct y2 = mult(y, y), y3 = mult(y2, y), y4 = mult(y2, y2), y8 = mult(y4, y4);
+    const int nl = y3.nl;
+    const double S = delta * (double)q[nl - 1];
+    Ct yd = clone(y);
+    drop_to(yd, nl);
+    Ct u = mul_const(yd, F4[1], S / yd.scale), t = mul_const(y3, F4[3], S / y3.scale);
+    u.scale = t.scale = S;
+    add_inplace(u, t);
+    rescale(u);
+    Ct v = mul_const(yd, F4[5], S / yd.scale);
+    t = mul_const(y3, F4[7], S / y3.scale);
+    v.scale = t.scale = S;
+    add_inplace(v, t);
+    rescale(v);
+    const double S0 = delta * (double)q[y.nl - 1];
+    Ct w = mul_const(y, F4[9], S0 / y.scale);
+    w.scale = S0;
+    rescale(w);
+    Ct a = mult(v, y4), b = mult(w, y8);
+    const int fl = std::min(std::min(a.nl, b.nl), u.nl);
+    drop_to(a, fl);
+    drop_to(b, fl);
+    drop_to(u, fl);
+    add_inplace(a, b);
+    add_inplace(a, u);
+    add_const(a, 1.0);  // :182
+    return a;
+}
+
+// indexScenario (sender_diag.cpp:52-63): one comparator pass over the batch of all G score ciphertexts
+Ct Context::index_scenario(const Ct &qc) {
+    Ct s = similarity(qc);
+    return chebyshev_compare(s, 0.44 /* MATCH_THRESHOLD, include/config.h:9 */, 10 /* COMP_DEPTH, :14 */);
+}
+// membershipScenario (sender_diag.cpp:35-50): EvalAddManyInPlace over blocks, then EvalSum over all slots
+Ct Context::membership_scenario(const Ct &qc) {
+    Ct s = index_scenario(qc);
+    return sum_and_evalsum(s);
+}
+Ct Context::sum_and_evalsum(const Ct &s) {
+    Ct m(this, 1, 2, s.nl, s.scale);
+    HIP_CHECK(hipMemcpyAsync(m.d, s.d, m.bytes(), hipMemcpyDeviceToDevice, stream));
+    for (int g = 1; g < s.X; g++) {
+        Ct v;
+        v.ctx = this; v.d = s.d + (size_t)g * s.ct_elems(); v.X = 1; v.npoly = 2; v.nl = s.nl; v.scale = s.scale; v.view = true;
+        add_inplace(m, v);
+    }
+    for (int r = 1; r < slots; r <<= 1) {
+        Ct t = rotate(m, r);
+        add_inplace(m, t);
+    }
+    return m;
+}
+
+}  // namespace hydia

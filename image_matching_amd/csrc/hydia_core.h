@@ -1,0 +1,171 @@
+// image_matching_amd/csrc/hydia_core.h — host side of libhydia: RNS context, device tables, HBM pool, batched
+// ciphertext evaluator and the HyDia sender/receiver/enroller engines behind the C-ABI of include/hydia.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));           \
+    } while (0)
+
+namespace hydia {
+
+struct Params {
+    int logN = 15, mult_depth = 11, scale_bits = 45, first_bits = 60, dnum = 3, dim = 512;
+};
+
+// Caching HBM allocator: every evaluator temporary comes from here; all work is on ONE stream so a freed block
+// can be handed to the next request without synchronisation.
+class Pool {
+  public:
+    ~Pool();
+    u64 *get(size_t bytes);
+    void put(u64 *p);
+    void trim();
+    size_t bytes_live = 0, bytes_cached = 0, peak = 0;
+
+  private:
+    std::multimap<size_t, u64 *> free_;
+    std::map<u64 *, size_t> size_;
+};
+
+struct Context;
+
+// A batch of X ciphertexts of identical shape, [X][npoly][nl][N], evaluation form, resident in HBM.
+struct Ct {
+    Context *ctx = nullptr;
+    u64 *d = nullptr;
+    int X = 0, npoly = 0, nl = 0;
+    double scale = 0;
+    bool view = false;  // does not own d
+    Ct() = default;
+    Ct(Context *c, int X_, int npoly_, int nl_, double scale_);
+    Ct(const Ct &) = delete;
+    Ct &operator=(const Ct &) = delete;
+    Ct(Ct &&o) noexcept { *this = std::move(o); }
+    Ct &operator=(Ct &&o) noexcept;
+    ~Ct();
+    size_t ct_elems() const;
+    size_t bytes() const { return ct_elems() * X * sizeof(u64); }
+};
+
+struct KernelTimer {
+    double total_ms = 0;
+    long launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+// Host-only part: parameter derivation and conversion constants (no GPU needed; `hydia_params_describe` uses it).
+struct HostParams {
+    Params prm;
+    int N, slots, nQ, nP, nT, alpha;
+    double delta;
+    std::vector<u64> q, psi;
+    std::vector<ModC> mod;
+    std::vector<u64> P_mod_q, Pinv_mod_q, Phat_inv;
+    std::vector<std::vector<u64>> Phat_mod_q;  // [k][j]
+    std::vector<std::vector<u64>> ql_inv;      // [l][j]
+    explicit HostParams(const Params &p);
+    void twiddles(int m, std::vector<u64> &tw, std::vector<u64> &tws, std::vector<u64> &itw, std::vector<u64> &itws) const;
+};
+
+struct Context : HostParams {
+    int device;
+    hipStream_t stream = nullptr;
+    Pool pool;
+
+    // device tables
+    ModC *d_mod = nullptr;
+    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr;
+    NttTables tabs{};
+
+    // evaluation keys resident in HBM: [dnum][2][nT][N]; each carries a one-element device cell holding its own
+    // address and Galois element so single-key launches need no per-call upload
+    struct EvalKey {
+        u64 *d = nullptr;
+        const u64 **d_cell = nullptr;
+        unsigned *d_gal = nullptr;
+    };
+    EvalKey relin_key;
+    std::map<int, EvalKey> rot_keys;
+    const u64 **d_rotptrs = nullptr;   // device array: key pointers of rotations 1..dim-1 (hoisted loop A)
+    unsigned *d_rotgalois = nullptr;   // device array: their Galois elements
+    bool rotptrs_valid = false;
+    void load_eval_key(int rot /* 0 = relinearisation */, const u64 *host);
+    u64 *eval_key_storage(int rot);    // allocates (or returns) the HBM buffer of key `rot`
+    u64 *d_sk = nullptr;               // [nT][N] (receiver side only)
+    u64 *d_pk = nullptr;               // [2][nQ][N]
+
+    // encrypted database resident in HBM: [G*dim][2][nQ][N]
+    u64 *d_db = nullptr;
+    size_t db_vectors = 0, db_cts = 0;
+
+    std::map<std::string, KernelTimer> timers;
+    bool timing = true;
+
+    explicit Context(const Params &p, int device);
+    ~Context();
+    void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+
+    // ---- helpers
+    LimbSel sel_q(int nl) const;           // limbs 0..nl-1
+    LimbSel sel_ext(int nl) const;         // limbs 0..nl-1 then all P limbs
+    LimbSel sel_range(int lo, int hi) const;
+    ScaleSel scale_ninv(const LimbSel &s) const;                   // N^{-1}
+    ScaleSel scale_of(const LimbSel &s, const std::vector<u64> &v, bool times_ninv) const;
+    u64 galois_elt(int rot) const;
+
+    // ---- primitive evaluator ops (all asynchronous on `stream`)
+    void ntt_fwd(u64 *base, size_t outer, int X, const LimbSel &s);
+    void ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc);
+    // ModUp: c [X][nl][N] at stride c_outer -> dig [X][nd][nE][N]
+    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig);
+    // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
+    void ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
+                  const u64 *addend, size_t add_x_stride, int add_polys, const unsigned *d_galois, int same_galois,
+                  u64 *out);
+    void build_rotptrs();
+    void relinearize(Ct &c);  // [X][3][nl] -> [X][2][nl]
+    void rescale(Ct &c);      // drop the last limb
+    Ct clone(const Ct &a);
+    void drop_to(Ct &a, int nl);
+    void add_inplace(Ct &a, const Ct &b);
+    void sub_inplace(Ct &a, const Ct &b);
+    void add_const(Ct &a, double c);
+    Ct mul_const(const Ct &a, double c, double const_scale);
+    Ct mult_norelin(const Ct &a, const Ct &b);
+    Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale
+    Ct rotate(const Ct &a, int rot);    // X = any; full key switch
+
+    // ---- HyDia sender (src/sender/sender_diag.cpp)
+    Ct rotate_query(const Ct &q);                   // -> [dim][2][nQ][N]
+    Ct similarity(const Ct &q);                     // -> [G][2][nQ-1][N]
+    Ct chebyshev_compare(const Ct &x, double delta, int sign_depth);
+    Ct index_scenario(const Ct &q);
+    Ct membership_scenario(const Ct &q);
+    Ct sum_and_evalsum(const Ct &s);  // EvalAddMany over the batch + EvalSum over all slots
+
+    // timing of named kernels (HIP events on `stream`)
+    void timer_begin(const char *name);
+    void timer_end(const char *name);
+    void timer_collect();
+};
+
+// host residue of a real constant (value already multiplied by its scale)
+u64 double_to_mod(double v, u64 q);
+u64 powmod_u64(u64 a, u64 e, u64 q);
+u64 invmod_u64(u64 a, u64 q);
+u64 mulmod_u64(u64 a, u64 b, u64 q);
+
+}  // namespace hydia

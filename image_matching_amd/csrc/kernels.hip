@@ -1,0 +1,399 @@
+// image_matching_amd/csrc/kernels.hip — hand-written gfx950 kernels of the HyDia sender hot path.
+//
+// What each kernel replaces (reference call sites; the arithmetic itself is OpenFHE's, un-vendored):
+//   k_ntt_*               every NTT/INTT inside EvalFastRotation / Relinearize / Rescale
+//                         (/root/reference/src/sender/sender_diag.cpp:22-26, :79-80)
+//   k_base_convert        ModUp / ModDown fast base conversion of hybrid key switching (same call sites)
+//   k_inner_product       <digits, evk> of EvalFastRotation (sender_diag.cpp:25) and RelinearizeInPlace (:79)
+//   k_moddown_combine     ModDown's (acc - conv) / P, + c0, + the evaluation-form automorphism of EvalFastRotation
+//   k_hydia_tensor        512 x EvalMultNoRelin + 511 x EvalAddInPlace per block (sender_diag.cpp:70-77, :93)
+//   k_rescale_*           RescaleInPlace (sender_diag.cpp:80)
+// No MFMA: this is 64-bit integer modular arithmetic.  HBM-streaming kernels read 16 B per lane (1 KiB per wave
+// instruction) of one limb, so modulus constants are wave-uniform.
+#include "kernels.h"
+
+namespace {
+
+DEV unsigned brev_n(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
+
+// ------------------------------------------------------------------------------------------------ NTT
+// N = 2^logN = R * 256.  Forward = strided pass (first logN-8 stages, stride >= 256, a workgroup owns 32 adjacent
+// columns x all R rows in LDS) then contiguous pass (last 8 stages inside 256-blocks; a workgroup owns 2048
+// consecutive coefficients).  Inverse runs the two passes in the opposite order with Gentleman-Sande butterflies.
+template <bool INV>
+__global__ __launch_bounds__(256) void k_ntt_strided(NttTables T, int logN, const u64 *__restrict__ src,
+                                                     u64 *__restrict__ dst, size_t so, size_t dso, LimbSel sel,
+                                                     ScaleSel scale) {
+    extern __shared__ u64 lds[];
+    const int N = 1 << logN, logR = logN - 8, R = 1 << logR;
+    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n, m = sel.mod[slot];
+    const u64 q = T.mod[m].q;
+    const u64 *s = src + (size_t)x * so + (size_t)slot * N;
+    u64 *d = dst + (size_t)x * dso + (size_t)slot * N;
+    const int c0 = blockIdx.x * 32, tid = threadIdx.x;
+    for (int e = tid; e < R * 32; e += 256) lds[e] = s[(size_t)(e >> 5) * 256 + c0 + (e & 31)];
+    __syncthreads();
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)m * N;
+    const u64 *tws = (INV ? T.itw_sh : T.tw_sh) + (size_t)m * N;
+    for (int st = 0; st < logR; st++) {
+        const int lt = INV ? st : logR - 1 - st;           // log2 of the row stride
+        const int base = INV ? (R >> (st + 1)) : (1 << st);  // twiddle block of this stage
+        for (int e = tid; e < (R >> 1) * 32; e += 256) {
+            const int c = e & 31, k = e >> 5;
+            const int i = k >> lt, o = k & ((1 << lt) - 1);
+            const int r0 = (i << (lt + 1)) + o, r1 = r0 + (1 << lt);
+            const u64 W = tw[base + i], Ws = tws[base + i];
+            const u64 U = lds[r0 * 32 + c], V = lds[r1 * 32 + c];
+            if (!INV) {
+                const u64 Vw = mulmod_shoup(V, W, Ws, q);
+                lds[r0 * 32 + c] = addmod(U, Vw, q);
+                lds[r1 * 32 + c] = submod(U, Vw, q);
+            } else {
+                lds[r0 * 32 + c] = addmod(U, V, q);
+                lds[r1 * 32 + c] = mulmod_shoup(submod(U, V, q), W, Ws, q);
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < R * 32; e += 256) {
+        u64 v = lds[e];
+        if (INV) v = mulmod_shoup(v, scale.s[slot], scale.s_sh[slot], q);
+        d[(size_t)(e >> 5) * 256 + c0 + (e & 31)] = v;
+    }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256) void k_ntt_contig(NttTables T, int logN, const u64 *__restrict__ src,
+                                                    u64 *__restrict__ dst, size_t so, size_t dso, LimbSel sel) {
+    __shared__ u64 lds[2048];
+    const int N = 1 << logN;
+    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n, m = sel.mod[slot];
+    const u64 q = T.mod[m].q;
+    const int B0 = blockIdx.x * 2048, tid = threadIdx.x;
+    const u64 *s = src + (size_t)x * so + (size_t)slot * N + B0;
+    u64 *d = dst + (size_t)x * dso + (size_t)slot * N + B0;
+    for (int k = 0; k < 4; k++) {
+        const int idx = 2 * tid + 512 * k;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(s + idx);
+        lds[idx] = v.x;
+        lds[idx + 1] = v.y;
+    }
+    __syncthreads();
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)m * N;
+    const u64 *tws = (INV ? T.itw_sh : T.tw_sh) + (size_t)m * N;
+    for (int st = 0; st < 8; st++) {
+        const int lt = INV ? st : 7 - st;  // log2 of the stride inside the chunk
+        const int base = (INV ? (N >> (lt + 1)) : (N >> (lt + 1))) + (B0 >> (lt + 1));
+        // forward stage with stride t uses block mm = N/(2t); inverse stage with stride t uses block h = N/(2t)
+        for (int e = tid; e < 1024; e += 256) {
+            const int i = e >> lt, o = e & ((1 << lt) - 1);
+            const int l0 = (i << (lt + 1)) + o, l1 = l0 + (1 << lt);
+            const u64 W = tw[base + i], Ws = tws[base + i];
+            const u64 U = lds[l0], V = lds[l1];
+            if (!INV) {
+                const u64 Vw = mulmod_shoup(V, W, Ws, q);
+                lds[l0] = addmod(U, Vw, q);
+                lds[l1] = submod(U, Vw, q);
+            } else {
+                lds[l0] = addmod(U, V, q);
+                lds[l1] = mulmod_shoup(submod(U, V, q), W, Ws, q);
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < 4; k++) {
+        const int idx = 2 * tid + 512 * k;
+        ulonglong2 v;
+        v.x = lds[idx];
+        v.y = lds[idx + 1];
+        *reinterpret_cast<ulonglong2 *>(d + idx) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise
+// grid: (N/512, X*sel.n); each thread 2 coefficients (16 B)
+#define EW_PROLOGUE                                                                         \
+    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n;                          \
+    const ModC M = mod[sel.mod[slot]];                                                      \
+    const size_t off = ((size_t)x * sel.n + slot) * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_addsub(const ModC *__restrict__ mod, int N, const u64 *a, const u64 *b, u64 *o,
+                                                LimbSel sel) {  // a, b, o may alias (in-place add, doubling)
+    EW_PROLOGUE
+    const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + off);
+    const ulonglong2 vb = *reinterpret_cast<const ulonglong2 *>(b + off);
+    ulonglong2 r;
+    r.x = OP == 0 ? addmod(va.x, vb.x, M.q) : submod(va.x, vb.x, M.q);
+    r.y = OP == 0 ? addmod(va.y, vb.y, M.q) : submod(va.y, vb.y, M.q);
+    *reinterpret_cast<ulonglong2 *>(o + off) = r;
+}
+__global__ __launch_bounds__(256) void k_mul_scalar(const ModC *__restrict__ mod, int N, const u64 *__restrict__ a,
+                                                    u64 *__restrict__ o, LimbSel sel, ScaleSel c) {
+    EW_PROLOGUE
+    const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + off);
+    ulonglong2 r;
+    r.x = mulmod_shoup(va.x, c.s[slot], c.s_sh[slot], M.q);
+    r.y = mulmod_shoup(va.y, c.s[slot], c.s_sh[slot], M.q);
+    *reinterpret_cast<ulonglong2 *>(o + off) = r;
+}
+__global__ __launch_bounds__(256) void k_add_scalar(const ModC *__restrict__ mod, int N, u64 *__restrict__ a,
+                                                    size_t outer, LimbSel sel, ScaleSel c) {
+    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n;
+    const u64 q = mod[sel.mod[slot]].q;
+    u64 *p = a + (size_t)x * outer + (size_t)slot * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    ulonglong2 v = *reinterpret_cast<ulonglong2 *>(p);
+    v.x = addmod(v.x, c.s[slot], q);
+    v.y = addmod(v.y, c.s[slot], q);
+    *reinterpret_cast<ulonglong2 *>(p) = v;
+}
+__global__ __launch_bounds__(256) void k_copy_limbs(int N, const u64 *__restrict__ src, u64 *__restrict__ dst,
+                                                    size_t so, size_t dso, int nlimbs) {
+    const int y = blockIdx.y, x = y / nlimbs, slot = y - x * nlimbs;
+    const size_t i = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    *reinterpret_cast<ulonglong2 *>(dst + (size_t)x * dso + (size_t)slot * N + i) =
+        *reinterpret_cast<const ulonglong2 *>(src + (size_t)x * so + (size_t)slot * N + i);
+}
+// EvalMultNoRelin on X pairs: grid (N/512, nl, X)
+__global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ a,
+                                                const u64 *__restrict__ b, u64 *__restrict__ o, int nl) {
+    const int j = blockIdx.y, x = blockIdx.z;
+    const ModC M = mod[j];
+    const size_t i = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t pa = ((size_t)x * 2 * nl + j) * N + i, ps = (size_t)nl * N;
+    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(a + pa), a1 = *reinterpret_cast<const ulonglong2 *>(a + pa + ps);
+    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(b + pa), b1 = *reinterpret_cast<const ulonglong2 *>(b + pa + ps);
+    ulonglong2 d0, d1, d2;
+    d0.x = mulmod(a0.x, b0.x, M);
+    d0.y = mulmod(a0.y, b0.y, M);
+    d1.x = reduce128((u128)a0.x * b1.x + (u128)a1.x * b0.x, M);
+    d1.y = reduce128((u128)a0.y * b1.y + (u128)a1.y * b0.y, M);
+    d2.x = mulmod(a1.x, b1.x, M);
+    d2.y = mulmod(a1.y, b1.y, M);
+    const size_t po = ((size_t)x * 3 * nl + j) * N + i;
+    *reinterpret_cast<ulonglong2 *>(o + po) = d0;
+    *reinterpret_cast<ulonglong2 *>(o + po + ps) = d1;
+    *reinterpret_cast<ulonglong2 *>(o + po + 2 * ps) = d2;
+}
+
+// ------------------------------------------------------------------------------------------------ key switching
+// grid (N/256, nt, X)
+__global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
+                                                      size_t yo, u64 *__restrict__ out, size_t oo, ConvTab tab,
+                                                      LimbSel dsel) {
+    const int t = blockIdx.y, x = blockIdx.z;
+    if (t >= tab.skip_lo && t < tab.skip_hi) return;
+    const ModC M = mod[dsel.mod[t]];
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u128 acc = 0;
+    for (int s = 0; s < tab.ns; s++) acc += (u128)y[(size_t)x * yo + (size_t)s * N + c] * tab.f[s][t];
+    out[(size_t)x * oo + (size_t)t * N + c] = reduce128(acc, M);
+}
+// grid (N/512, nE, X); 2 coefficients per thread, both key polys
+__global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ mod, int N, const u64 *__restrict__ dig,
+                                                       size_t dxs, int nd, const u64 *const *__restrict__ keys,
+                                                       int same_key, int nT, u64 *__restrict__ acc, LimbSel esel) {
+    const int t = blockIdx.y, x = blockIdx.z, nE = esel.n, m = esel.mod[t];
+    const ModC M = mod[m];
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const u64 *key = keys[same_key ? 0 : x];
+    u128 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
+    for (int d = 0; d < nd; d++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(dig + (size_t)x * dxs + ((size_t)d * nE + t) * N + c);
+        const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 0) * nT + m) * N + c);
+        const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 1) * nT + m) * N + c);
+        a0x += (u128)v.x * kb.x;
+        a0y += (u128)v.y * kb.y;
+        a1x += (u128)v.x * ka.x;
+        a1y += (u128)v.y * ka.y;
+    }
+    ulonglong2 r0, r1;
+    r0.x = reduce128(a0x, M);
+    r0.y = reduce128(a0y, M);
+    r1.x = reduce128(a1x, M);
+    r1.y = reduce128(a1y, M);
+    *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 0) * nE + t) * N + c) = r0;
+    *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 1) * nE + t) * N + c) = r1;
+}
+// grid (N/256, nl, X*2)
+__global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict__ mod, int logN,
+                                                         const u64 *__restrict__ acc, int acc_limbs,
+                                                         const u64 *__restrict__ conv, const u64 *__restrict__ addend,
+                                                         size_t axs, int add_polys, u64 *__restrict__ out, int nl,
+                                                         ScaleSel pinv, const unsigned *__restrict__ galois,
+                                                         int same_g) {
+    const int N = 1 << logN;
+    const int j = blockIdx.y, xp = blockIdx.z, x = xp >> 1, p = xp & 1;
+    const u64 q = mod[j].q;
+    const unsigned co = blockIdx.x * 256 + threadIdx.x;
+    unsigned c = co;
+    if (galois) {
+        const unsigned g = galois[same_g ? 0 : x];
+        if (g != 1u) {
+            const unsigned e = ((2u * brev_n(co, logN) + 1u) * g) & (2u * N - 1u);
+            c = brev_n((e - 1u) >> 1, logN);
+        }
+    }
+    u64 v = submod(acc[((size_t)xp * acc_limbs + j) * N + c], conv[((size_t)xp * nl + j) * N + c], q);
+    v = mulmod_shoup(v, pinv.s[j], pinv.s_sh[j], q);
+    if (addend && p < add_polys) v = addmod(v, addend[(size_t)x * axs + ((size_t)p * nl + j) * N + c], q);
+    out[((size_t)xp * nl + j) * N + co] = v;
+}
+// grid (N/256, l, X)
+__global__ __launch_bounds__(256) void k_rescale_spread(const ModC *__restrict__ mod, int N, const u64 *__restrict__ t,
+                                                        u64 *__restrict__ tmp, int l) {
+    const int j = blockIdx.y, x = blockIdx.z;
+    const ModC M = mod[j];
+    const u64 ql = mod[l].q, half = ql >> 1;
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u64 v = t[(size_t)x * N + c];
+    tmp[((size_t)x * l + j) * N + c] = v > half ? negmod(reduce64(ql - v, M), M.q) : reduce64(v, M);
+}
+__global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict__ mod, int N, const u64 *__restrict__ in,
+                                                         const u64 *__restrict__ tmp, u64 *__restrict__ out, int l,
+                                                         ScaleSel qlinv) {
+    const int j = blockIdx.y, x = blockIdx.z;
+    const u64 q = mod[j].q;
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u64 v = submod(in[((size_t)x * (l + 1) + j) * N + c], tmp[((size_t)x * l + j) * N + c], q);
+    out[((size_t)x * l + j) * N + c] = mulmod_shoup(v, qlinv.s[j], qlinv.s_sh[j], q);
+}
+
+// ------------------------------------------------------------------------------------------------ loop B
+// acc[g][{d0,d1,d2}][j][c] = sum_{i<dim} rot[i] (x) db[g][i] with 128-bit lazy accumulation: one double-word
+// Barrett per output instead of 4*dim reductions.  45/46-bit limbs never overflow (dim * 2^93 < 2^128); the 60-bit
+// limb folds its accumulators every 64 diagonals.  grid (N/512, nl, G): 16 B per lane per operand.
+__global__ __launch_bounds__(256) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
+                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, int dim,
+                                                      int nl) {
+    const int j = blockIdx.y, g = blockIdx.z;
+    const ModC M = mod[j];
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t ps = (size_t)nl * N, cs = 2 * ps;  // poly stride, ciphertext stride
+    const u64 *ra = rot + (size_t)j * N + c;
+    const u64 *da = db + (size_t)g * dim * cs + (size_t)j * N + c;
+    const int kbits = M.ks + 2;
+    const int chunk = (126 - 2 * kbits >= 30) ? dim : (1 << (126 - 2 * kbits));
+    u128 d0x = 0, d0y = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
+    for (int i0 = 0; i0 < dim; i0 += chunk) {
+        const int i1 = i0 + chunk < dim ? i0 + chunk : dim;
+#pragma unroll 4
+        for (int i = i0; i < i1; i++) {
+            const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
+            const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs + ps);
+            const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(da + (size_t)i * cs);
+            const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(da + (size_t)i * cs + ps);
+            d0x += (u128)a0.x * b0.x;
+            d0y += (u128)a0.y * b0.y;
+            d1x += (u128)a0.x * b1.x + (u128)a1.x * b0.x;
+            d1y += (u128)a0.y * b1.y + (u128)a1.y * b0.y;
+            d2x += (u128)a1.x * b1.x;
+            d2y += (u128)a1.y * b1.y;
+        }
+        if (i1 < dim) {
+            d0x = reduce128(d0x, M); d0y = reduce128(d0y, M);
+            d1x = reduce128(d1x, M); d1y = reduce128(d1y, M);
+            d2x = reduce128(d2x, M); d2y = reduce128(d2y, M);
+        }
+    }
+    ulonglong2 r0, r1, r2;
+    r0.x = reduce128(d0x, M); r0.y = reduce128(d0y, M);
+    r1.x = reduce128(d1x, M); r1.y = reduce128(d1y, M);
+    r2.x = reduce128(d2x, M); r2.y = reduce128(d2y, M);
+    u64 *o = acc + ((size_t)g * 3 * nl + j) * N + c;
+    *reinterpret_cast<ulonglong2 *>(o) = r0;
+    *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
+    *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
+}
+
+__global__ __launch_bounds__(256) void k_fill_uniform_hash(const ModC *__restrict__ mod, int N, u64 *__restrict__ dst,
+                                                           int nl, u64 seed) {
+    const size_t lp = blockIdx.y + (size_t)blockIdx.z * gridDim.y;
+    const ModC M = mod[lp % nl];
+    const size_t idx = lp * N + (size_t)blockIdx.x * 256 + threadIdx.x;
+    u64 z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    dst[idx] = reduce64(z, M);
+}
+
+}  // namespace
+
+// ================================================================================================ launchers
+namespace hk {
+
+void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
+                 const LimbSel &sel) {
+    const int N = 1 << logN, R = N >> 8;
+    ScaleSel dummy = {};
+    hipLaunchKernelGGL(k_ntt_strided<false>, dim3(8, X * sel.n), dim3(256), (size_t)R * 32 * 8, st, T, logN, src, dst, so,
+                       dso, sel, dummy);
+    hipLaunchKernelGGL(k_ntt_contig<false>, dim3(N / 2048, X * sel.n), dim3(256), 0, st, T, logN, dst, dst, dso, dso, sel);
+}
+void ntt_inverse(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
+                 const LimbSel &sel, const ScaleSel &scale) {
+    const int N = 1 << logN, R = N >> 8;
+    hipLaunchKernelGGL(k_ntt_contig<true>, dim3(N / 2048, X * sel.n), dim3(256), 0, st, T, logN, src, dst, so, dso, sel);
+    hipLaunchKernelGGL(k_ntt_strided<true>, dim3(8, X * sel.n), dim3(256), (size_t)R * 32 * 8, st, T, logN, dst, dst, dso,
+                       dso, sel, scale);
+}
+void add(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, const LimbSel &sel) {
+    hipLaunchKernelGGL(k_addsub<0>, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel);
+}
+void sub(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, const LimbSel &sel) {
+    hipLaunchKernelGGL(k_addsub<1>, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel);
+}
+void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, int X, const LimbSel &sel,
+                const ScaleSel &c) {
+    hipLaunchKernelGGL(k_mul_scalar, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, o, sel, c);
+}
+void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,
+                const ScaleSel &c) {
+    hipLaunchKernelGGL(k_add_scalar, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, outer, sel, c);
+}
+void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t so, size_t dso, int X, int nlimbs) {
+    hipLaunchKernelGGL(k_copy_limbs, dim3(N / 512, X * nlimbs), dim3(256), 0, st, N, src, dst, so, dso, nlimbs);
+}
+void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl) {
+    hipLaunchKernelGGL(k_tensor, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl);
+}
+void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, u64 *out, size_t oo, int X,
+                  const ConvTab &tab, const LimbSel &dsel) {
+    hipLaunchKernelGGL(k_base_convert, dim3(N / 256, tab.nt, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
+}
+void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
+                   int same_key, int nT, u64 *acc, int X, const LimbSel &esel) {
+    hipLaunchKernelGGL(k_inner_product, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
+                       nT, acc, esel);
+}
+void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
+                     const u64 *addend, size_t axs, int add_polys, u64 *out, int X, int nl, const ScaleSel &pinv,
+                     const unsigned *galois, int same_g) {
+    hipLaunchKernelGGL(k_moddown_combine, dim3((1 << logN) / 256, nl, X * 2), dim3(256), 0, st, mod, logN, acc, acc_limbs,
+                       conv, addend, axs, add_polys, out, nl, pinv, galois, same_g);
+}
+void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l) {
+    hipLaunchKernelGGL(k_rescale_spread, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, t, tmp, l);
+}
+void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, const u64 *tmp, u64 *out, int X, int l,
+                     const ScaleSel &qlinv) {
+    hipLaunchKernelGGL(k_rescale_combine, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, in, tmp, out, l, qlinv);
+}
+void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
+                             int dim, int nl) {
+    hipLaunchKernelGGL(k_hydia_tensor, dim3(N / 512, nl, G), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl);
+}
+const char *hydia_tensor_kernel_name() { return "k_hydia_tensor"; }
+void fill_uniform_hash(hipStream_t st, const ModC *mod, int N, u64 *dst, size_t n_limbpolys, int nl,
+                       unsigned long long seed) {
+    // slabs of at most 32768 limb-polys (grid.y limit), each starting on a limb-0 boundary
+    const size_t slab = 32768 - 32768 % nl;
+    for (size_t done = 0; done < n_limbpolys; done += slab) {
+        const size_t cnt = n_limbpolys - done < slab ? n_limbpolys - done : slab;
+        hipLaunchKernelGGL(k_fill_uniform_hash, dim3(N / 256, (unsigned)cnt, 1), dim3(256), 0, st, mod, N,
+                           dst + done * N, nl, seed + done * 0x51ED27ull);
+    }
+}
+
+}  // namespace hk

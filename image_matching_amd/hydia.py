@@ -1,0 +1,431 @@
+"""ctypes host layer over libhydia.so (include/hydia.h).
+
+Mirrors the reference's class surface for approach 5 so parity tests read like the reference's driver
+(/root/reference/src/main.cpp:302-374):
+    DiagonalEnroller(cc, n).serializeDB(db)            include/enroller_diag.h:7-27
+    DiagonalReceiver(cc, n).encryptQuery(q) / decryptMembership(ct) / decryptIndex(cts)   include/receiver.h:17-43
+    DiagonalSender(cc, n).computeSimilarity / membershipScenario / indexScenario          include/sender.h:19-43
+`cc` is a Context (replaces CryptoContext + keys).  There is no CPU fallback: a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class HydiaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hydia error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("log_n", "mult_depth", "scale_bits", "first_mod_bits", "dnum", "vector_dim")]
+
+
+class _Info(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("log_n", "n", "slots", "n_q", "n_p", "dnum", "alpha", "vector_dim")] + [
+        ("delta", C.c_double)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhydia.so")
+
+
+def build_library():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")])
+
+
+def load_library():
+    """Load libhydia.so; raises if it has not been built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HydiaError(-3, "libhydia.so is not built (%s missing): run __graft_entry__.build() or "
+                             "make -C image_matching_amd/csrc" % path)
+    L = C.CDLL(path)
+    vp, u64, sz, dbl, i32, u32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_double, C.c_int, C.c_uint32
+    pp = C.POINTER(C.c_void_p)
+    sig = {
+        "hydia_last_error": (C.c_char_p, []),
+        "hydia_version": (C.c_char_p, []),
+        "hydia_default_params": (None, [C.POINTER(_Params)]),
+        "hydia_params_describe": (i32, [C.POINTER(_Params), C.POINTER(_Info), vp, vp]),
+        "hydia_compute_required_depth": (sz, [sz]),
+        "hydia_ctx_create": (i32, [C.POINTER(_Params), i32, pp]),
+        "hydia_ctx_destroy": (None, [vp]),
+        "hydia_get_info": (i32, [vp, C.POINTER(_Info)]),
+        "hydia_get_moduli": (i32, [vp, vp, vp]),
+        "hydia_sync": (i32, [vp]),
+        "hydia_memory_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "hydia_keygen": (i32, [vp, vp]),
+        "hydia_import_eval_key": (i32, [vp, i32, vp]),
+        "hydia_export_eval_key": (i32, [vp, i32, vp]),
+        "hydia_import_public_key": (i32, [vp, vp]),
+        "hydia_import_secret_key": (i32, [vp, vp]),
+        "hydia_export_public_key": (i32, [vp, vp]),
+        "hydia_export_secret_key": (i32, [vp, vp]),
+        "hydia_has_eval_key": (i32, [vp, i32]),
+        "hydia_fill_eval_keys_random": (i32, [vp, u64]),
+        "hydia_ct_import": (i32, [vp, vp, u32, u32, u32, dbl, pp]),
+        "hydia_ct_export": (i32, [vp, vp, vp]),
+        "hydia_ct_shape": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(dbl)]),
+        "hydia_ct_device_ptr": (i32, [vp, pp, C.POINTER(sz)]),
+        "hydia_ct_from_device": (i32, [vp, vp, u32, u32, u32, dbl, pp]),
+        "hydia_ct_free": (None, [vp]),
+        "hydia_encrypt_query": (i32, [vp, vp, vp, u64, pp]),
+        "hydia_encrypt": (i32, [vp, vp, u32, vp, u64, pp]),
+        "hydia_decrypt": (i32, [vp, vp, vp]),
+        "hydia_decrypt_membership": (i32, [vp, vp, C.POINTER(i32)]),
+        "hydia_decrypt_index": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "hydia_db_num_cts": (sz, [vp, sz]),
+        "hydia_db_enroll": (i32, [vp, vp, sz, vp]),
+        "hydia_db_alloc": (i32, [vp, sz]),
+        "hydia_db_import_ct": (i32, [vp, sz, vp]),
+        "hydia_db_export_ct": (i32, [vp, sz, vp]),
+        "hydia_db_fill_random": (i32, [vp, sz, u64]),
+        "hydia_db_stats": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+        "hydia_rotate_query": (i32, [vp, vp, pp]),
+        "hydia_compute_similarity": (i32, [vp, vp, pp]),
+        "hydia_index_scenario": (i32, [vp, vp, pp]),
+        "hydia_membership_scenario": (i32, [vp, vp, pp]),
+        "hydia_chebyshev_compare": (i32, [vp, vp, dbl, sz, pp]),
+        "hydia_sum_and_evalsum": (i32, [vp, vp, pp]),
+        "hydia_ntt": (i32, [vp, vp, u32, u32, i32]),
+        "hydia_eval_rotate": (i32, [vp, vp, i32, pp]),
+        "hydia_eval_mult": (i32, [vp, vp, vp, pp]),
+        "hydia_eval_mult_no_relin": (i32, [vp, vp, vp, pp]),
+        "hydia_relinearize": (i32, [vp, vp]),
+        "hydia_rescale": (i32, [vp, vp]),
+        "hydia_eval_add": (i32, [vp, vp, vp]),
+        "hydia_level_reduce": (i32, [vp, vp, u32]),
+        "hydia_kernel_time": (i32, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(u64)]),
+        "hydia_kernel_time_reset": (i32, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    L._hydia_symbols = sorted(sig)
+    _LIB = L
+    return L
+
+
+def _chk(code):
+    if code != 0:
+        raise HydiaError(code, load_library().hydia_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _seed(x):
+    if isinstance(x, (bytes, bytearray)):
+        b = bytes(x)
+        assert len(b) == 32
+    else:
+        b = int(x).to_bytes(32, "little")
+    return np.frombuffer(b, dtype=np.uint8).copy()
+
+
+def default_params(**over):
+    p = _Params()
+    load_library().hydia_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def compute_required_depth(approach):
+    """OpenFHEWrapper::computeRequiredDepth (src/openFHE_wrapper.cpp:6-44)."""
+    return int(load_library().hydia_compute_required_depth(approach))
+
+
+def describe_params(params=None):
+    """Host-only: (info dict, moduli, roots) of a parameter set — works without a GPU."""
+    L = load_library()
+    p = params or default_params()
+    info = _Info()
+    mod = np.zeros(64, dtype=np.uint64)
+    roots = np.zeros(64, dtype=np.uint64)
+    _chk(L.hydia_params_describe(C.byref(p), C.byref(info), _p(mod), _p(roots)))
+    nt = info.n_q + info.n_p
+    d = {k: getattr(info, k) for k, _ in _Info._fields_}
+    return d, mod[:nt].copy(), roots[:nt].copy()
+
+
+class Ciphertext:
+    """Handle of a batch of ciphertexts resident in HBM (Ciphertext<DCRTPoly> / vector<Ciphertext<DCRTPoly>>)."""
+
+    def __init__(self, cc, h):
+        self.cc, self.h = cc, h
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.cc.h:
+            self.cc.L.hydia_ct_free(self.h)
+            self.h = None
+
+    def shape(self):
+        c, p, l, s = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+        _chk(self.cc.L.hydia_ct_shape(self.h, C.byref(c), C.byref(p), C.byref(l), C.byref(s)))
+        return c.value, p.value, l.value, s.value
+
+    def __len__(self):
+        return self.shape()[0]
+
+    size = __len__
+
+    def export(self):
+        c, p, l, _ = self.shape()
+        out = np.zeros((c, p, l, self.cc.N), dtype=np.uint64)
+        _chk(self.cc.L.hydia_ct_export(self.cc.h, self.h, _p(out)))
+        return out
+
+    def device_ptr(self):
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _chk(self.cc.L.hydia_ct_device_ptr(self.h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+
+class Context:
+    """CKKS context + keys + resident database on one GPU (replaces CryptoContext<DCRTPoly>, src/main.cpp:169-206)."""
+
+    def __init__(self, params=None, device=0):
+        self.L = load_library()
+        self.params = params or default_params()
+        h = C.c_void_p()
+        _chk(self.L.hydia_ctx_create(C.byref(self.params), device, C.byref(h)))
+        self.h = h
+        info = _Info()
+        _chk(self.L.hydia_get_info(self.h, C.byref(info)))
+        self.info = info
+        self.N, self.slots, self.nQ, self.nP, self.dnum, self.dim = info.n, info.slots, info.n_q, info.n_p, info.dnum, info.vector_dim
+        self.nT = self.nQ + self.nP
+        self.delta = info.delta
+        self.moduli = np.zeros(self.nT, dtype=np.uint64)
+        self.roots = np.zeros(self.nT, dtype=np.uint64)
+        _chk(self.L.hydia_get_moduli(self.h, _p(self.moduli), _p(self.roots)))
+
+    def close(self):
+        if self.h:
+            self.L.hydia_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(self.L.hydia_sync(self.h))
+
+    # ---- keys
+    def keygen(self, seed):
+        _chk(self.L.hydia_keygen(self.h, _p(_seed(seed))))
+
+    def import_eval_key(self, rot, data):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        assert data.size == self.dnum * 2 * self.nT * self.N
+        _chk(self.L.hydia_import_eval_key(self.h, rot, _p(data)))
+
+    def export_eval_key(self, rot):
+        out = np.zeros((self.dnum, 2, self.nT, self.N), dtype=np.uint64)
+        _chk(self.L.hydia_export_eval_key(self.h, rot, _p(out)))
+        return out
+
+    def import_public_key(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        assert data.size == 2 * self.nQ * self.N
+        _chk(self.L.hydia_import_public_key(self.h, _p(data)))
+
+    def import_secret_key(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        assert data.size == self.nT * self.N
+        _chk(self.L.hydia_import_secret_key(self.h, _p(data)))
+
+    def export_public_key(self):
+        out = np.zeros((2, self.nQ, self.N), dtype=np.uint64)
+        _chk(self.L.hydia_export_public_key(self.h, _p(out)))
+        return out
+
+    def export_secret_key(self):
+        out = np.zeros((self.nT, self.N), dtype=np.uint64)
+        _chk(self.L.hydia_export_secret_key(self.h, _p(out)))
+        return out
+
+    def fill_eval_keys_random(self, seed=1):
+        _chk(self.L.hydia_fill_eval_keys_random(self.h, seed))
+
+    def has_eval_key(self, rot):
+        return bool(self.L.hydia_has_eval_key(self.h, rot))
+
+    # ---- ciphertexts
+    def import_ct(self, data, scale):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        if data.ndim == 3:
+            data = data[None]
+        c, p, l, n = data.shape
+        assert n == self.N
+        h = C.c_void_p()
+        _chk(self.L.hydia_ct_import(self.h, _p(data), c, p, l, scale, C.byref(h)))
+        return Ciphertext(self, h)
+
+    def ct_from_device(self, ptr, count, n_polys, n_limbs, scale):
+        h = C.c_void_p()
+        _chk(self.L.hydia_ct_from_device(self.h, C.c_void_p(ptr), count, n_polys, n_limbs, scale, C.byref(h)))
+        return Ciphertext(self, h)
+
+    def _out(self, fn, *args):
+        h = C.c_void_p()
+        _chk(fn(self.h, *args, C.byref(h)))
+        return Ciphertext(self, h)
+
+    def encrypt(self, slots, seed, nonce0=0):
+        slots = np.ascontiguousarray(slots, dtype=np.float64)
+        if slots.ndim == 1:
+            slots = slots[None]
+        assert slots.shape[1] == self.slots
+        return self._out(self.L.hydia_encrypt, _p(slots), slots.shape[0], _p(_seed(seed)), nonce0)
+
+    def decrypt(self, ct):
+        out = np.zeros((len(ct), self.slots), dtype=np.float64)
+        _chk(self.L.hydia_decrypt(self.h, ct.h, _p(out)))
+        return out
+
+    # ---- primitives
+    def ntt(self, data, modulus_index, inverse=False):
+        a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+        a2 = a.reshape(-1, self.N)
+        _chk(self.L.hydia_ntt(self.h, _p(a2), a2.shape[0], modulus_index, int(inverse)))
+        return a
+
+    def eval_rotate(self, ct, rot):
+        return self._out(self.L.hydia_eval_rotate, ct.h, rot)
+
+    def eval_mult(self, a, b):
+        return self._out(self.L.hydia_eval_mult, a.h, b.h)
+
+    def eval_mult_no_relin(self, a, b):
+        return self._out(self.L.hydia_eval_mult_no_relin, a.h, b.h)
+
+    def relinearize(self, ct):
+        _chk(self.L.hydia_relinearize(self.h, ct.h))
+
+    def rescale(self, ct):
+        _chk(self.L.hydia_rescale(self.h, ct.h))
+
+    def eval_add(self, a, b):
+        _chk(self.L.hydia_eval_add(self.h, a.h, b.h))
+
+    def level_reduce(self, ct, n_limbs):
+        _chk(self.L.hydia_level_reduce(self.h, ct.h, n_limbs))
+
+    def chebyshev_compare(self, ct, delta=0.44, depth=10):
+        """OpenFHEWrapper::chebyshevCompare (src/openFHE_wrapper.cpp:143-185)."""
+        return self._out(self.L.hydia_chebyshev_compare, ct.h, delta, depth)
+
+    def sum_and_evalsum(self, ct):
+        return self._out(self.L.hydia_sum_and_evalsum, ct.h)
+
+    # ---- database
+    def db_num_cts(self, n):
+        return int(self.L.hydia_db_num_cts(self.h, n))
+
+    def db_alloc(self, n):
+        _chk(self.L.hydia_db_alloc(self.h, n))
+
+    def db_import_ct(self, t, data):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        assert data.size == 2 * self.nQ * self.N
+        _chk(self.L.hydia_db_import_ct(self.h, t, _p(data)))
+
+    def db_export_ct(self, t):
+        out = np.zeros((2, self.nQ, self.N), dtype=np.uint64)
+        _chk(self.L.hydia_db_export_ct(self.h, t, _p(out)))
+        return out
+
+    def db_fill_random(self, n, seed=1):
+        _chk(self.L.hydia_db_fill_random(self.h, n, seed))
+
+    def db_stats(self):
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _chk(self.L.hydia_db_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- measurement
+    def kernel_time(self, name):
+        ms, n = C.c_double(), C.c_uint64()
+        _chk(self.L.hydia_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        _chk(self.L.hydia_kernel_time_reset(self.h))
+
+    def memory_stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(self.L.hydia_memory_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+
+class DiagonalEnroller:
+    """include/enroller_diag.h:7-27 — ctor (cc, pk, numVectors); pk lives inside the Context here."""
+
+    def __init__(self, cc, num_vectors):
+        self.cc, self.numVectors = cc, num_vectors
+
+    def serializeDB(self, database, seed=0):
+        """DiagonalEnroller::serializeDB (src/enroller/enroller_diag.cpp:12-53).  Normalises `database` IN PLACE like
+        the reference; the ciphertexts go straight into HBM instead of serial/db_diagonal/index<t>.bin."""
+        assert database.dtype == np.float64 and database.flags.c_contiguous
+        assert database.shape == (self.numVectors, self.cc.dim)
+        _chk(self.cc.L.hydia_db_enroll(self.cc.h, _p(database), self.numVectors, _p(_seed(seed))))
+
+
+class DiagonalReceiver:
+    """include/receiver_diag.h:7-16 + inherited HersReceiver::decrypt* (src/receiver/receiver_hers.cpp:26-54)."""
+
+    def __init__(self, cc, num_vectors):
+        self.cc, self.numVectors = cc, num_vectors
+
+    def encryptQuery(self, query, seed=0, nonce=1):
+        query = np.ascontiguousarray(query, dtype=np.float64)
+        assert query.shape == (self.cc.dim,)
+        return self.cc._out(self.cc.L.hydia_encrypt_query, _p(query), _p(_seed(seed)), nonce)
+
+    def decryptMembership(self, membership_cipher):
+        r = C.c_int()
+        _chk(self.cc.L.hydia_decrypt_membership(self.cc.h, membership_cipher.h, C.byref(r)))
+        return bool(r.value)
+
+    def decryptIndex(self, index_cipher):
+        cap = len(index_cipher) * self.cc.slots
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        _chk(self.cc.L.hydia_decrypt_index(self.cc.h, index_cipher.h, _p(out), cap, C.byref(n)))
+        return [int(v) for v in out[:n.value]]
+
+
+class DiagonalSender:
+    """include/sender_diag.h:5-28 — the three virtuals of include/sender.h:28-35."""
+
+    def __init__(self, cc, num_vectors):
+        self.cc, self.numVectors = cc, num_vectors
+
+    def rotateQuery(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_rotate_query, query_cipher.h)
+
+    def computeSimilarity(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_compute_similarity, query_cipher.h)
+
+    def membershipScenario(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_membership_scenario, query_cipher.h)
+
+    def indexScenario(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_index_scenario, query_cipher.h)

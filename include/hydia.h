@@ -1,0 +1,168 @@
+/*
+ * include/hydia.h — C-ABI of libhydia.so: the MI355X-native drop-in for the HyDia (approach 5) path of
+ * n7koirala/image_matching.  Plain pointers and sizes only; no torch / OpenFHE / C++ types cross this boundary.
+ *
+ * The reference has no FFI: its seam is the C++ virtual surface main.cpp programs against
+ * (/root/reference/include/sender.h:19-43, include/receiver.h:17-43, include/enroller_diag.h:7-27), carrying OpenFHE
+ * shared_ptr handles.  Each entry point below names the reference interface it replaces; INTEGRATION.md shows the
+ * adapter a maintainer adds on the reference side.
+ *
+ * Data crossing the boundary:
+ *   ciphertext  = uint64 residues, limb-major [poly][limb][N], EVALUATION form in bit-reversed order
+ *                 (out[j] = a(psi^(2*bitrev(j)+1)) mod q_limb), limb j <-> modulus j of hydia_get_moduli();
+ *                 what OpenFHE exposes as ct->GetElements()[p].GetElementAtIndex(j).GetValues() after
+ *                 SetFormat(EVALUATION) when the moduli/roots agree (otherwise cross in COEFFICIENT form via
+ *                 hydia_ct_import_coeff).
+ *   eval key    = [digit][2][limb over Q then P][N] residues, poly 0 = b, poly 1 = a (hybrid key switching, dnum digits)
+ *   slots       = IEEE doubles
+ * All functions return 0 on success and a negative hydia_status otherwise; hydia_last_error() has the message
+ * (the reference prints to cerr and carries on — src/sender/sender_diag.cpp:89-91 — callers that want that behaviour
+ * ignore the code).  One host thread per context; contexts are independent (one per GPU).
+ */
+#ifndef HYDIA_H
+#define HYDIA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HYDIA_OK = 0,
+    HYDIA_ERR_ARG = -1,      /* bad argument / shape */
+    HYDIA_ERR_STATE = -2,    /* missing key / database / wrong level */
+    HYDIA_ERR_DEVICE = -3,   /* HIP failure (no GPU, out of memory, ...) */
+    HYDIA_ERR_INTERNAL = -4
+} hydia_status;
+
+/* CKKS parameters — the knobs of /root/reference/src/main.cpp:169-173 plus VECTOR_DIM (include/config.h:30). */
+typedef struct {
+    uint32_t log_n;          /* 15  (HEStd_128_classic at this modulus size) */
+    uint32_t mult_depth;     /* 11  = OpenFHEWrapper::computeRequiredDepth(5), src/openFHE_wrapper.cpp:37-40 */
+    uint32_t scale_bits;     /* 45  SetScalingModSize */
+    uint32_t first_mod_bits; /* 60  OpenFHE default first modulus */
+    uint32_t dnum;           /* 3   OpenFHE default numLargeDigits (HYBRID) */
+    uint32_t vector_dim;     /* 512 VECTOR_DIM */
+} hydia_params;
+
+typedef struct {
+    uint32_t log_n, n, slots, n_q, n_p, dnum, alpha, vector_dim;
+    double delta;            /* 2^scale_bits */
+} hydia_info;
+
+typedef struct hydia_ctx hydia_ctx;
+typedef struct hydia_ct hydia_ct; /* a batch of >= 1 ciphertexts of identical shape, resident in HBM */
+
+const char *hydia_last_error(void);
+const char *hydia_version(void);
+
+/* hydia_default_params: the context of ./ImageMatching <file> 5 (src/main.cpp:82, :169-173). */
+void hydia_default_params(hydia_params *out);
+/* Host-only parameter derivation (no GPU needed): moduli/roots are length n_q + n_p, Q limbs first. */
+int hydia_params_describe(const hydia_params *p, hydia_info *info, uint64_t *moduli, uint64_t *roots);
+/* OpenFHEWrapper::computeRequiredDepth, src/openFHE_wrapper.cpp:6-44 */
+size_t hydia_compute_required_depth(size_t approach);
+
+/* replaces GenCryptoContext + Enable(...) (src/main.cpp:169-179) for the sender/receiver on GPU `device` */
+int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out);
+void hydia_ctx_destroy(hydia_ctx *ctx);
+int hydia_get_info(const hydia_ctx *ctx, hydia_info *out);
+int hydia_get_moduli(const hydia_ctx *ctx, uint64_t *moduli, uint64_t *roots);
+int hydia_sync(hydia_ctx *ctx);
+int hydia_memory_stats(hydia_ctx *ctx, uint64_t *pool_live, uint64_t *pool_cached, uint64_t *pool_peak);
+
+/* ---- keys: cc->KeyGen / EvalMultKeyGen / EvalRotateKeyGen (src/main.cpp:184-206) ---- */
+/* generate sk, pk, relin key and rotation keys {1..dim-1} u {dim, 2dim, .., slots/2} on the GPU from a 32-byte seed */
+int hydia_keygen(hydia_ctx *ctx, const uint8_t seed[32]);
+/* or import keys produced elsewhere (the reference's serial/*.bin contents after unmarshalling):
+ * rot = 0 is the relinearisation key, rot >= 1 the key of EvalRotate(., rot); data [dnum][2][n_q+n_p][N] */
+int hydia_import_eval_key(hydia_ctx *ctx, int rot, const uint64_t *data);
+int hydia_export_eval_key(hydia_ctx *ctx, int rot, uint64_t *data);
+int hydia_import_public_key(hydia_ctx *ctx, const uint64_t *data /* [2][n_q][N] (b, a) */);
+int hydia_import_secret_key(hydia_ctx *ctx, const uint64_t *data /* [n_q+n_p][N], evaluation form */);
+int hydia_export_public_key(hydia_ctx *ctx, uint64_t *data);
+int hydia_export_secret_key(hydia_ctx *ctx, uint64_t *data);
+int hydia_has_eval_key(hydia_ctx *ctx, int rot);
+/* profiling filler: relin + rotation keys {1..dim-1} u {dim..slots/2 powers of two} of uniformly random residues
+ * (kernel cost is data independent; results decrypt to noise) */
+int hydia_fill_eval_keys_random(hydia_ctx *ctx, uint64_t seed);
+
+/* ---- ciphertext handles (Ciphertext<DCRTPoly>) ---- */
+int hydia_ct_import(hydia_ctx *ctx, const uint64_t *data, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
+                    double scale, hydia_ct **out);
+int hydia_ct_export(hydia_ctx *ctx, const hydia_ct *ct, uint64_t *data);
+int hydia_ct_shape(const hydia_ct *ct, uint32_t *count, uint32_t *n_polys, uint32_t *n_limbs, double *scale);
+/* raw HBM address of the batch (for RCCL gathers through torch.distributed; layout [count][poly][limb][N]) */
+int hydia_ct_device_ptr(const hydia_ct *ct, void **ptr, size_t *bytes);
+int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
+                         double scale, hydia_ct **out); /* copies */
+void hydia_ct_free(hydia_ct *ct);
+
+/* ---- receiver: DiagonalReceiver / HersReceiver ---- */
+/* Receiver::encryptQuery, src/receiver/receiver_diag.cpp:13-26: normalise, tile to all slots, encode, encrypt */
+int hydia_encrypt_query(hydia_ctx *ctx, const double *query /* vector_dim */, const uint8_t seed[32], uint64_t nonce,
+                        hydia_ct **out);
+/* OpenFHEWrapper::encryptFromVector, src/openFHE_wrapper.cpp:74-77 (count vectors of `slots` doubles each) */
+int hydia_encrypt(hydia_ctx *ctx, const double *slots, uint32_t count, const uint8_t seed[32], uint64_t nonce0,
+                  hydia_ct **out);
+/* OpenFHEWrapper::decryptToVector, src/openFHE_wrapper.cpp:81-85: out = count * slots doubles */
+int hydia_decrypt(hydia_ctx *ctx, const hydia_ct *ct, double *out);
+/* HersReceiver::decryptMembership, src/receiver/receiver_hers.cpp:26-35: slot 0 >= 1.0 */
+int hydia_decrypt_membership(hydia_ctx *ctx, const hydia_ct *ct, int *result);
+/* HersReceiver::decryptIndex, src/receiver/receiver_hers.cpp:37-54: every slot >= 1.0 -> j + i*slots.
+ * *n_out receives the number of matches; at most cap are written. */
+int hydia_decrypt_index(hydia_ctx *ctx, const hydia_ct *cts, size_t *out, size_t cap, size_t *n_out);
+
+/* ---- enroller: DiagonalEnroller ---- */
+/* number of DB ciphertexts for n vectors (concatenateRows, src/enroller/enroller_diag.cpp:120-122) */
+size_t hydia_db_num_cts(const hydia_ctx *ctx, size_t n_vectors);
+/* DiagonalEnroller::serializeDB, src/enroller/enroller_diag.cpp:12-53: normalises db IN PLACE (like the reference),
+ * diagonalises, encodes and encrypts straight into the HBM-resident layout (no serial/db_diagonal files).
+ * first_vector/total_vectors select the row-block shard this GPU owns: rows [first_vector, first_vector+n) of a
+ * total_vectors database (pass 0 / n for a single GPU). */
+int hydia_db_enroll(hydia_ctx *ctx, double *db /* n x vector_dim row-major */, size_t n, const uint8_t seed[32]);
+/* or load ciphertexts produced elsewhere: t = block*vector_dim + diagonal, i.e. serial/db_diagonal/index<t>.bin
+ * (src/enroller/enroller_diag.cpp:161; read back at src/sender/sender_diag.cpp:87-91) */
+int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors);
+int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data /* [2][n_q][N] */);
+int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data);
+/* benchmark filler: n_vectors worth of uniformly random residues (the kernels' cost is data independent) */
+int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed);
+int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_t *bytes);
+
+/* ---- sender: DiagonalSender (src/sender/sender_diag.cpp) ---- */
+/* loop A alone (:20-26): the vector_dim rotated queries, rot[0] = q */
+int hydia_rotate_query(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+/* Sender::computeSimilarity (:12-33): one score ciphertext per 16384-vector block, level 1 */
+int hydia_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+/* Sender::indexScenario (:52-63) */
+int hydia_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+/* Sender::membershipScenario (:35-50) */
+int hydia_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+/* OpenFHEWrapper::chebyshevCompare (src/openFHE_wrapper.cpp:143-185) on every ciphertext of the batch */
+int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *in, double delta, size_t sign_depth, hydia_ct **out);
+/* multi-GPU membership tail: sum the batch into one ciphertext, then EvalSum over all slots (:46-47) */
+int hydia_sum_and_evalsum(hydia_ctx *ctx, const hydia_ct *in, hydia_ct **out);
+
+/* ---- evaluator primitives (used by the parity tests and by adapters) ---- */
+int hydia_ntt(hydia_ctx *ctx, uint64_t *data /* host, [count][N] in place */, uint32_t count, uint32_t modulus_index,
+              int inverse);
+int hydia_eval_rotate(hydia_ctx *ctx, const hydia_ct *in, int rot, hydia_ct **out);
+int hydia_eval_mult(hydia_ctx *ctx, const hydia_ct *a, const hydia_ct *b, hydia_ct **out); /* mult+relin+rescale */
+int hydia_eval_mult_no_relin(hydia_ctx *ctx, const hydia_ct *a, const hydia_ct *b, hydia_ct **out);
+int hydia_relinearize(hydia_ctx *ctx, hydia_ct *ct);
+int hydia_rescale(hydia_ctx *ctx, hydia_ct *ct);
+int hydia_eval_add(hydia_ctx *ctx, hydia_ct *a, const hydia_ct *b);
+int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs);
+
+/* ---- measurement: HIP-event time of named kernels on the context's stream since the last reset
+ * ("hydia_tensor" = loop B's tensor-accumulate kernel, "ks_inner_product") ---- */
+int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
+int hydia_kernel_time_reset(hydia_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

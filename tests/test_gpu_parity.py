@@ -1,0 +1,197 @@
+"""GPU parity (run with -m gpu on an MI355X): every HIP path is called through the C-ABI (include/hydia.h) and
+compared BIT-EXACTLY with the CPU oracle on the same inputs — all of it is integer arithmetic, so the bar is
+equality, not a tolerance.  Decrypted scores are additionally checked against plaintext cosine to the reference's
+own 1e-4 (src/main_accuracy.cpp:359-360).  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def im():
+    import image_matching_amd as im
+    return im
+
+
+def make_ctx(im, P):
+    prm = im.default_params(log_n=P.log_n, mult_depth=P.nQ - 1, vector_dim=P.dim, dnum=P.dnum)
+    cc = im.Context(prm, 0)
+    assert np.array_equal(cc.moduli, P.moduli) and np.array_equal(cc.roots, P.roots)
+    return cc
+
+
+def load_keys(cc, K, rotations):
+    cc.import_eval_key(0, K.relin())
+    for r in rotations:
+        cc.import_eval_key(r, K.rot_key(r))
+    cc.import_public_key(K.pk())
+    cc.import_secret_key(K.s_ntt())
+
+
+def load_db(cc, dbc, n):
+    cc.db_alloc(n)
+    assert cc.db_num_cts(n) == len(dbc)
+    for t in range(len(dbc)):
+        cc.db_import_ct(t, dbc[t].data())
+
+
+@pytest.fixture(scope="module")
+def small(im):
+    P = O.Params(log_n=11, depth=11, dim=64)
+    K = O.Keys(P, 7)
+    cc = make_ctx(im, P)
+    load_keys(cc, K, K.rotations)
+    yield P, K, O.Oracle(P, K), cc
+    cc.close()
+
+
+@pytest.mark.parametrize("log_n", [11, 13, 15])
+def test_ntt_bit_exact(im, log_n):
+    P = O.Params(log_n=log_n, depth=11, dim=64)
+    cc = make_ctx(im, P)
+    rng = np.random.default_rng(log_n)
+    for m in (0, 1, 6, 11, 12, 15):
+        q = int(P.moduli[m])
+        a = rng.integers(0, q, size=(3, P.N), dtype=np.uint64)
+        a[1] = q - 1
+        a[2, 1:] = 0
+        want = np.stack([P.ntt_fwd(row, m) for row in a])
+        got = cc.ntt(a, m)
+        assert np.array_equal(got, want), (log_n, m)
+        assert np.array_equal(cc.ntt(got, m, inverse=True), a)
+        want_inv = np.stack([P.ntt_inv(row, m) for row in a])
+        assert np.array_equal(cc.ntt(a, m, inverse=True), want_inv)
+    cc.close()
+
+
+def test_evaluator_primitives_bit_exact(small):
+    P, K, Or, cc = small
+    rng = np.random.default_rng(1)
+    z, w = rng.uniform(-1, 1, P.slots), rng.uniform(-1, 1, P.slots)
+    a, b = Or.encrypt(z, 1, 1), Or.encrypt(w, 1, 2)
+    ga, gb = cc.import_ct(a.data(), a.scale), cc.import_ct(b.data(), b.scale)
+    # EvalMultNoRelin / Relinearize / Rescale
+    d = Or.mult_norelin(a, b)
+    gd = cc.eval_mult_no_relin(ga, gb)
+    assert np.array_equal(gd.export()[0], d.data())
+    Or.relin(d); cc.relinearize(gd)
+    assert np.array_equal(gd.export()[0], d.data())
+    Or.rescale(d); cc.rescale(gd)
+    assert np.array_equal(gd.export()[0], d.data()) and gd.shape()[2] == P.nQ - 1
+    assert abs(gd.shape()[3] / d.scale - 1) < 1e-15
+    # rotations (full key switch) incl. partial digits at lower levels
+    for r in (1, 5, 63, 64, 512):
+        assert np.array_equal(cc.eval_rotate(ga, r).export()[0], Or.rotate(a, r).data()), r
+    cur, gcur = a, ga
+    while cur.nl > 1:
+        cur, gcur = Or.mult(cur, cur), cc.eval_mult(gcur, gcur)
+        assert np.array_equal(gcur.export()[0], cur.data()), cur.nl
+    assert np.array_equal(cc.eval_rotate(gcur, 8).export()[0], Or.rotate(cur, 8).data())
+    # a batch of two ciphertexts behaves like two single ones
+    both = cc.import_ct(np.stack([a.data(), b.data()]), a.scale)
+    sq = cc.eval_mult(both, both).export()
+    assert np.array_equal(sq[0], Or.mult(a, a).data()) and np.array_equal(sq[1], Or.mult(b, b).data())
+
+
+@pytest.mark.parametrize("n,matches", [(1500, [0, 700, 1499]), (64, [63]), (1, [0]), (1024, []), (1025, [1024])])
+def test_hydia_sender_bit_exact_small_ring(im, small, n, matches):
+    P, K, Or, cc = small
+    rng = np.random.default_rng(n)
+    db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
+    for i in matches:
+        db[i] = rng.integers(1, 4, size=P.dim)
+    query = np.ones(P.dim)
+    nrm = np.linalg.norm(db, axis=1, keepdims=True)
+    cos = (db / nrm) @ (query / np.linalg.norm(query))
+    dbc = Or.enroll(db.copy(), 99)
+    load_db(cc, dbc, n)
+    q = Or.encrypt_query(query, 5, 1)
+    gq = cc.import_ct(q.data(), q.scale)
+    sender = im.DiagonalSender(cc, n)
+    # loop A
+    rot, grot = Or.rotate_query(q), sender.rotateQuery(gq).export()
+    for i in range(P.dim):
+        assert np.array_equal(grot[i], rot[i].data()), i
+    # computeSimilarity
+    sim, gsim = Or.compute_similarity(q, dbc, n), sender.computeSimilarity(gq)
+    G = -(-n // P.slots)
+    assert gsim.shape()[:3] == (G, 2, P.nQ - 1)
+    gs = gsim.export()
+    for g in range(G):
+        assert np.array_equal(gs[g], sim[g].data())
+    scores = np.concatenate([Or.decrypt(sim[g]) for g in range(G)])
+    assert np.abs(scores[:n] - cos).max() < TOL
+    # indexScenario / membershipScenario
+    idx, gidx = Or.index_scenario(q, dbc, n), sender.indexScenario(gq)
+    gi = gidx.export()
+    for g in range(G):
+        assert np.array_equal(gi[g], idx[g].data())
+    assert Or.decrypt_index(idx) == sorted(matches)
+    mem, gmem = Or.membership_scenario(q, dbc, n), sender.membershipScenario(gq)
+    assert np.array_equal(gmem.export()[0], mem.data())
+    assert Or.decrypt_membership(mem) == (len(matches) > 0)
+
+
+def test_comparator_depths_and_guard(small):
+    P, K, Or, cc = small
+    x = np.linspace(-1, 1, P.slots)
+    ct = Or.encrypt(x, 3, 1)
+    P.L.hyo_drop_to(P.h, ct.h, P.nQ - 1)
+    g = cc.import_ct(ct.data(), ct.scale)
+    for depth in (7, 8, 9, 10):
+        assert np.array_equal(cc.chebyshev_compare(g, 0.44, depth).export()[0], Or.chebyshev_compare(ct, 0.44, depth).data())
+    same = cc.chebyshev_compare(g, 0.44, 6)  # openFHE_wrapper.cpp:146-149
+    assert np.array_equal(same.export()[0], ct.data())
+
+
+def test_error_behaviour(im, small):
+    P, K, Or, cc = small
+    fresh = make_ctx(im, P)
+    q = Or.encrypt_query(np.ones(P.dim), 5, 1)
+    gq = fresh.import_ct(q.data(), q.scale)
+    with pytest.raises(im.HydiaError) as e:  # no rotation keys / no database
+        im.DiagonalSender(fresh, 10).computeSimilarity(gq)
+    assert e.value.code == -2
+    with pytest.raises(im.HydiaError):
+        fresh.import_ct(np.zeros((1, 5, 2, P.N), dtype=np.uint64), 1.0)
+    fresh.close()
+
+
+def test_reference_dataset_2_10_full_ring(im):
+    """BASELINE config 1/2: ./ImageMatching ../test/2_10.dat 5 on N = 2^15 — GPU sender vs oracle, bit exact, and
+    the reference's expected answers: membership true, index [0], scores within 1e-4 of plaintext cosine."""
+    P = O.Params()
+    K = O.Keys(P, 20250725)
+    Or = O.Oracle(P, K)
+    cc = make_ctx(im, P)
+    load_keys(cc, K, K.rotations)
+    g = np.load(os.path.join(GOLDEN, "dataset_2_10.npz"))
+    n, query, db = int(g["n"]), g["query"].astype(np.float64), g["db"].astype(np.float64)
+    dbc = Or.enroll(db, 99)
+    load_db(cc, dbc, n)
+    q = Or.encrypt_query(query, 5, 1)
+    gq = cc.import_ct(q.data(), q.scale)
+    sender = im.DiagonalSender(cc, n)
+    sim = Or.compute_similarity(q, dbc, n)
+    gsim = sender.computeSimilarity(gq)
+    assert np.array_equal(gsim.export()[0], sim[0].data())
+    scores = Or.decrypt(sim[0])
+    assert np.abs(scores[:n] - g["cosine"]).max() < TOL
+    cmp_ct = Or.chebyshev_compare(sim[0], 0.44, 10)
+    gidx = sender.indexScenario(gq)
+    assert np.array_equal(gidx.export()[0], cmp_ct.data())
+    vals = Or.decrypt(cmp_ct)
+    assert [int(i) for i in np.nonzero(vals >= 1.0)[0]] == [0]
+    # decrypt the GPU membership ciphertext with the oracle's secret key
+    gmem = sender.membershipScenario(gq)
+    gm = O.Ct(P, P.L.hyo_ct_alloc(P.h, 2, 1, gmem.shape()[3]))
+    gm.data()[:] = gmem.export()[0]
+    assert Or.decrypt_membership(gm) is True
+    cc.close()
