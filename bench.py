@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — encrypted DB vectors matched/sec (HyDia, CKKS N = 2^15) on N MI355X of one node.
+
+A "step" is ONE query through DiagonalSender::indexScenario (/root/reference/src/sender/sender_diag.cpp:52-63: 511 hoisted
+rotations, per block 512 tensor products + 1 relinearise + 1 rescale, degree-59 Chebyshev o f4 comparator) over the
+encrypted database resident in this rank's HBM, plus — for N > 1 — the RCCL gather of the result ciphertexts to rank 0.
+The database is sharded by 16384-vector row-blocks: every rank owns its own blocks and runs an independent mat-vec
+(no data-path collective); per-GPU work is fixed as N grows ("weak").  Data is synthetic with the distribution of the
+reference's tools/gen_dataset.sh (query = ones, random rows in [-99,99], planted matches in {1,2,3}); the database is
+REAL ciphertexts produced by the on-GPU enroller, and after the timed region the decrypted index result is checked
+against the planted matches.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20250725
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_db(n, dim, rank, planted):
+    """tools/gen_dataset.sh distribution: rows uniform integers in [-99, 99]; matching rows uniform in {1,2,3}."""
+    rng = np.random.default_rng(SEED + 1000 * rank)
+    db = rng.integers(-99, 100, size=(n, dim), dtype=np.int8).astype(np.float64)
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=dim)
+    return db
+
+
+def cpu_baseline(dim_full=512):
+    """Time the CPU oracle (the build's restatement of the reference algorithm; OpenFHE itself is absent) on this host:
+    one full indexScenario over ONE 16384-vector block at the real ring.  Only this leg touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    P = O.Params()
+    K = O.Keys(P, SEED)
+    Or = O.Oracle(P, K)
+    n = P.slots
+    db = synth_db(n, P.dim, 99, [5])
+    dbc = Or.enroll(db, 99)
+    q = Or.encrypt_query(np.ones(P.dim), 5, 1)
+    t0 = time.time()
+    rot = Or.rotate_query(q)
+    t_rot = time.time() - t0
+    del rot
+    t0 = time.time()
+    idx = Or.index_scenario(q, dbc, n)
+    t_index = time.time() - t0
+    ok = Or.decrypt_index(idx) == [5]
+    cores = O.lib().hyo_num_threads()
+    return {
+        "value": n / t_index, "unit": "vectors/s", "cores": int(cores), "kind": "port",
+        "sample": "one indexScenario over ONE 16384-vector block at N=2^15 (511 hoisted rotations + 512 tensor products + "
+                  "relin + rescale + compare): %.2f s, of which rotations %.2f s; OpenMP over the reference's loops; "
+                  "result %s" % (t_index, t_rot, "correct" if ok else "WRONG"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20, help="log2 of DB vectors PER GPU (default 2^20 = 192 GiB of ciphertexts)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--random-db", action="store_true", help="fill the DB with random residues instead of enrolling")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = torch = None
+    if world > 1:
+        import torch  # noqa: F811  (device memory + RCCL only)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import image_matching_amd as im
+    cc = im.Context(im.default_params(), local_rank)
+    n = 1 << args.log2n
+    dim, S = cc.dim, cc.slots
+    G = -(-n // S)
+
+    t0 = time.time()
+    cc.keygen(SEED)  # same seed on every rank -> identical keys, no key distribution needed
+    t_keygen = time.time() - t0
+    planted = sorted(set([0, n // 2, n - 1])) if n > 2 else [0]
+    t0 = time.time()
+    if args.random_db:
+        cc.db_fill_random(n, SEED + rank)
+    else:
+        db = synth_db(n, dim, rank, planted)
+        im.DiagonalEnroller(cc, n).serializeDB(db, seed=SEED + 7 * rank)
+        del db
+    t_enroll = time.time() - t0
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    qc = receiver.encryptQuery(np.ones(dim), seed=SEED, nonce=1)
+
+    gather_buf = gather_list = None
+
+    def step():
+        res = sender.indexScenario(qc)
+        if world > 1:
+            nonlocal gather_buf, gather_list
+            cnt, npoly, nl, _ = res.shape()
+            if gather_buf is None:
+                gather_buf = torch.empty(cnt * npoly * nl * cc.N, dtype=torch.int64, device="cuda")
+                gather_list = [torch.empty_like(gather_buf) for _ in range(world)] if rank == 0 else None
+            res.copy_to_device(gather_buf.data_ptr())
+            dist.gather(gather_buf, gather_list, dst=0)
+        return res
+
+    def fence():
+        cc.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    cc.kernel_time_reset()
+    t0 = time.time()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_tensor, launches = cc.kernel_time("hydia_tensor")
+    # correctness of what was just timed: decrypt this rank's index result (rank 0 also decrypts the gathered ones)
+    correct = True
+    if not args.random_db:
+        correct = receiver.decryptIndex(res) == planted
+        if world > 1 and rank == 0:
+            cnt, npoly, nl, scale = res.shape()
+            for r in range(1, world):
+                other = cc.ct_from_device(gather_list[r].data_ptr(), cnt, npoly, nl, scale)
+                correct = correct and receiver.decryptIndex(other) == planted
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        algo_bytes = (G * dim + dim) * 2 * cc.nQ * cc.N * 8 + G * 3 * cc.nQ * cc.N * 8
+        avg_launch_s = ms_tensor / max(launches, 1) / 1e3
+        achieved = algo_bytes / avg_launch_s / 1e9 if launches else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "tensor_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("log2n") == args.log2n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "encrypted DB vectors matched/sec (HyDia indexScenario, CKKS N=2^15)",
+            "value": world * n * args.steps / elapsed,
+            "unit": "vectors/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB per GPU (%d blocks of 16384, "
+                                   "%.0f GiB of ciphertexts resident in HBM), one query per step through indexScenario"
+                                   % (args.log2n, G, G * dim * 2 * cc.nQ * cc.N * 8 / 2 ** 30),
+                       "db_vectors_total": world * n, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
+                       "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3", "sharding": "row-block per GPU, RCCL gather of results",
+                       "result_check": "decrypted index == planted matches" if not args.random_db else "skipped (random DB)",
+                       "result_correct": bool(correct), "setup_s": {"keygen": round(t_keygen, 2), "enroll": round(t_enroll, 2)}},
+            "roofline": {"kernel": "k_hydia_tensor", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3,
+                         "launches": int(launches)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    cc.close()
+    if not correct:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

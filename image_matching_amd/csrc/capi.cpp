@@ -255,6 +255,14 @@ int hydia_ct_device_ptr(const hydia_ct *ct, void **ptr, size_t *bytes) {
     if (bytes) *bytes = ct->c.bytes();
     return HYDIA_OK;
 }
+int hydia_ct_copy_to_device(hydia_ctx *ctx, const hydia_ct *ct, void *dev_dst) {
+    API_BEGIN
+    REQUIRE(ctx && ct && dev_dst, "null argument");
+    HIP_CHECK(hipMemcpyAsync(dev_dst, ct->c.d, ct->c.bytes(), hipMemcpyDeviceToDevice, ctx->cx.stream));
+    ctx->cx.sync();
+    return HYDIA_OK;
+    API_END
+}
 int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
                          double scale, hydia_ct **out) {
     API_BEGIN

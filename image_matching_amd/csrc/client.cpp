@@ -1,10 +1,210 @@
-// placeholder until client_kernels.hip lands (next commit): every entry fails loudly, nothing falls back to the CPU
+// image_matching_amd/csrc/client.cpp — receiver / enroller / key generation engines on the GPU.
+//
+//   client_keygen         cc->KeyGen, EvalMultKeyGen, EvalRotateKeyGen           /root/reference/src/main.cpp:184-206
+//   client_encrypt        OpenFHEWrapper::encryptFromVector                      /root/reference/src/openFHE_wrapper.cpp:74-77
+//   client_encrypt_query  DiagonalReceiver::encryptQuery                         /root/reference/src/receiver/receiver_diag.cpp:13-26
+//   client_decrypt        OpenFHEWrapper::decryptToVector                        /root/reference/src/openFHE_wrapper.cpp:81-85
+//   client_enroll         DiagonalEnroller::serializeDB                          /root/reference/src/enroller/enroller_diag.cpp:12-53
+// All ring arithmetic, sampling and the canonical-embedding FFT run in HIP kernels; the host only normalises vectors
+// (VectorUtils::plaintextNormalize, /root/reference/src/vector_utils.cpp:32-51) and schedules launches.
 #include "client.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "client_kernels.h"
+
 namespace hydia {
-[[noreturn]] static void nyi(const char *w) { throw std::runtime_error(std::string("hydia: ") + w + " is not built in this revision"); }
-void client_keygen(Context &, const uint8_t[32]) { nyi("GPU key generation"); }
-Ct client_encrypt(Context &, const double *, int, const uint8_t[32], uint64_t) { nyi("GPU encryption"); }
-Ct client_encrypt_query(Context &, const double *, const uint8_t[32], uint64_t) { nyi("GPU query encryption"); }
-void client_decrypt(Context &, const Ct &, double *) { nyi("GPU decryption"); }
-void client_enroll(Context &, double *, size_t, const uint8_t[32]) { nyi("GPU enrolment"); }
+
+static ChaChaKey make_key(const uint8_t seed[32]) {
+    ChaChaKey k;
+    for (int i = 0; i < 8; i++)
+        k.k[i] = (unsigned)seed[4 * i] | ((unsigned)seed[4 * i + 1] << 8) | ((unsigned)seed[4 * i + 2] << 16) |
+                 ((unsigned)seed[4 * i + 3] << 24);
+    return k;
+}
+
+// canonical-embedding tables: 5^j mod 2N and exp(2 pi i k / 2N)
+static void ensure_embedding_tables(Context &cx) {
+    if (cx.d_rot_group) return;
+    const int M = 2 * cx.N;
+    std::vector<unsigned> rg(cx.slots);
+    u64 g = 1;
+    for (int j = 0; j < cx.slots; j++) {
+        rg[j] = (unsigned)g;
+        g = (g * 5) % (u64)M;
+    }
+    std::vector<double> ksi(2 * (size_t)(M + 1));
+    for (int k = 0; k <= M; k++) {
+        const double ang = 2.0 * M_PI * (double)k / (double)M;
+        ksi[2 * (size_t)k] = std::cos(ang);
+        ksi[2 * (size_t)k + 1] = std::sin(ang);
+    }
+    HIP_CHECK(hipMalloc((void **)&cx.d_rot_group, sizeof(unsigned) * rg.size()));
+    HIP_CHECK(hipMalloc((void **)&cx.d_ksi, sizeof(double) * ksi.size()));
+    HIP_CHECK(hipMemcpy(cx.d_rot_group, rg.data(), sizeof(unsigned) * rg.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(cx.d_ksi, ksi.data(), sizeof(double) * ksi.size(), hipMemcpyHostToDevice));
+}
+
+static u64 inv_mod_pow2(u64 g, u64 M) {
+    u64 x = 1;
+    for (int i = 0; i < 6; i++) x = x * (2 - g * x);
+    return x & (M - 1);
+}
+
+// hybrid switching key from secret s_from (Q limbs) to secret s_enc (Q u P limbs)
+static void gen_evk(Context &cx, const ChaChaKey &key, int key_id, const u64 *s_enc, const u64 *s_from) {
+    const int N = cx.N, nT = cx.nT, dnum = cx.prm.dnum;
+    u64 *evk = cx.eval_key_storage(key_id);
+    const LimbSel all = cx.sel_range(0, nT);
+    hc::sample_uniform(cx.stream, key, cx.d_mod, N, HY_STREAM(HY_DOM_EVK_A, key_id, 0, 0), 1ull, 1ull << 8,
+                       evk + (size_t)nT * N, (size_t)N, (size_t)2 * nT * N, all, dnum);
+    int *e32 = (int *)cx.pool.get(sizeof(int) * (size_t)dnum * N);
+    hc::sample_gauss(cx.stream, key, N, HY_STREAM(HY_DOM_EVK_E, key_id, 0, 0), 1ull << 8, e32, dnum);
+    u64 *e = cx.pool.get(sizeof(u64) * (size_t)dnum * nT * N);
+    hc::small_to_limbs(cx.stream, cx.d_mod, N, e32, nullptr, e, (size_t)nT * N, dnum, all);
+    cx.ntt_fwd(e, (size_t)nT * N, dnum, all);
+    ScaleSel pm{};
+    for (int j = 0; j < cx.nQ; j++) pm.s[j] = cx.P_mod_q[j];
+    hc::evk_combine(cx.stream, cx.d_mod, N, nT, cx.nQ, cx.alpha, dnum, evk, e, s_enc, s_from, pm);
+    cx.pool.put(e);
+    cx.pool.put((u64 *)e32);
+}
+
+void client_keygen(Context &cx, const uint8_t seed[32]) {
+    const int N = cx.N, nT = cx.nT, nQ = cx.nQ;
+    const ChaChaKey key = make_key(seed);
+    const LimbSel all = cx.sel_range(0, nT), qsel = cx.sel_q(nQ);
+    if (!cx.d_sk) HIP_CHECK(hipMalloc((void **)&cx.d_sk, sizeof(u64) * (size_t)nT * N));
+    if (!cx.d_pk) HIP_CHECK(hipMalloc((void **)&cx.d_pk, sizeof(u64) * (size_t)2 * nQ * N));
+    int *s32 = (int *)cx.pool.get(sizeof(int) * (size_t)N);
+    hc::sample_ternary(cx.stream, key, N, HY_STREAM(HY_DOM_SK, 0, 0, 0), 0, s32, 1);
+    hc::small_to_limbs(cx.stream, cx.d_mod, N, s32, nullptr, cx.d_sk, 0, 1, all);
+    cx.ntt_fwd(cx.d_sk, 0, 1, all);
+    // public key (b, a) = (-a s + e, a)
+    hc::sample_uniform(cx.stream, key, cx.d_mod, N, HY_STREAM(HY_DOM_PK_A, 0, 0, 0), 1ull, 0, cx.d_pk + (size_t)nQ * N,
+                       (size_t)N, 0, qsel, 1);
+    hc::sample_gauss(cx.stream, key, N, HY_STREAM(HY_DOM_PK_E, 0, 0, 0), 0, s32, 1);
+    hc::small_to_limbs(cx.stream, cx.d_mod, N, s32, nullptr, cx.d_pk, 0, 1, qsel);
+    cx.ntt_fwd(cx.d_pk, 0, 1, qsel);
+    hc::pk_combine(cx.stream, cx.d_mod, N, nQ, cx.d_pk, cx.d_pk + (size_t)nQ * N, cx.d_sk);
+    cx.pool.put((u64 *)s32);
+    // relinearisation key: s^2 -> s
+    u64 *tmp = cx.pool.get(sizeof(u64) * (size_t)nT * N);
+    hc::mul(cx.stream, cx.d_mod, N, cx.d_sk, cx.d_sk, tmp, qsel);
+    gen_evk(cx, key, 0, cx.d_sk, tmp);
+    // rotation keys {1..dim-1} u {dim, 2 dim, ... < slots}: key r switches s -> sigma_g^{-1}(s), g = 5^r, so
+    // EvalFastRotation needs a single automorphism at the very end (see evaluator.cpp, rotate_query)
+    std::vector<int> rots;
+    for (int i = 1; i < cx.prm.dim; i++) rots.push_back(i);
+    for (int i = cx.prm.dim; i < cx.slots; i <<= 1) rots.push_back(i);
+    const u64 M = 2ull * N;
+    for (int r : rots) {
+        const u64 ginv = inv_mod_pow2(cx.galois_elt(r), M);
+        hc::automorph(cx.stream, cx.prm.logN, cx.d_sk, tmp, (unsigned)ginv, nT);
+        gen_evk(cx, key, r, tmp, cx.d_sk);
+    }
+    cx.pool.put(tmp);
+    cx.sync();
+}
+
+// encode + encrypt X slot vectors that already sit in HBM; writes [X][2][nQ][N] at dst
+static void encrypt_device(Context &cx, const double *d_slots, int X, const ChaChaKey &key, u64 nonce0, u64 *dst) {
+    if (!cx.d_pk) throw std::runtime_error("hydia: public key not loaded");
+    ensure_embedding_tables(cx);
+    const int N = cx.N, nQ = cx.nQ, Nh = cx.slots;
+    const LimbSel qsel = cx.sel_q(nQ);
+    double2 *work = (double2 *)cx.pool.get(sizeof(double2) * (size_t)X * Nh);
+    long long *coeffs = (long long *)cx.pool.get(sizeof(long long) * (size_t)X * N);
+    hc::encode(cx.stream, d_slots, work, coeffs, N, X, cx.delta, cx.d_rot_group, (const double2 *)cx.d_ksi);
+    int *u32 = (int *)cx.pool.get(sizeof(int) * (size_t)X * N);
+    int *e0 = (int *)cx.pool.get(sizeof(int) * (size_t)X * N);
+    int *e1 = (int *)cx.pool.get(sizeof(int) * (size_t)X * N);
+    const u64 step = 1ull << 16;  // the nonce sits in stream-id field `a`
+    hc::sample_ternary(cx.stream, key, N, HY_STREAM(HY_DOM_ENC_U, nonce0, 0, 0), step, u32, X);
+    hc::sample_gauss(cx.stream, key, N, HY_STREAM(HY_DOM_ENC_E0, nonce0, 0, 0), step, e0, X);
+    hc::sample_gauss(cx.stream, key, N, HY_STREAM(HY_DOM_ENC_E1, nonce0, 0, 0), step, e1, X);
+    const size_t pe = (size_t)nQ * N;
+    u64 *U = cx.pool.get(sizeof(u64) * X * pe), *T0 = cx.pool.get(sizeof(u64) * X * pe), *T1 = cx.pool.get(sizeof(u64) * X * pe);
+    hc::small_to_limbs(cx.stream, cx.d_mod, N, u32, nullptr, U, pe, X, qsel);
+    hc::small_to_limbs(cx.stream, cx.d_mod, N, e0, coeffs, T0, pe, X, qsel);
+    hc::small_to_limbs(cx.stream, cx.d_mod, N, e1, nullptr, T1, pe, X, qsel);
+    cx.ntt_fwd(U, pe, X, qsel);
+    cx.ntt_fwd(T0, pe, X, qsel);
+    cx.ntt_fwd(T1, pe, X, qsel);
+    hc::enc_combine(cx.stream, cx.d_mod, N, nQ, cx.d_pk, U, T0, T1, dst, X);
+    for (void *p : {(void *)work, (void *)coeffs, (void *)u32, (void *)e0, (void *)e1, (void *)U, (void *)T0, (void *)T1})
+        cx.pool.put((u64 *)p);
+}
+
+Ct client_encrypt(Context &cx, const double *slots, int count, const uint8_t seed[32], uint64_t nonce0) {
+    const size_t bytes = sizeof(double) * (size_t)count * cx.slots;
+    double *d_slots = (double *)cx.pool.get(bytes);
+    HIP_CHECK(hipMemcpyAsync(d_slots, slots, bytes, hipMemcpyHostToDevice, cx.stream));
+    Ct out(&cx, count, 2, cx.nQ, cx.delta);
+    encrypt_device(cx, d_slots, count, make_key(seed), nonce0, out.d);
+    cx.pool.put((u64 *)d_slots);
+    cx.sync();  // `slots` is caller memory
+    return out;
+}
+
+// VectorUtils::plaintextNormalize (vector_utils.cpp:42-51): divide by the L2 norm, zero vector passes through
+static void normalize(double *x, int dim) {
+    double m = 0.0;
+    for (int i = 0; i < dim; i++) m += x[i] * x[i];
+    m = std::sqrt(m);
+    if (m != 0)
+        for (int i = 0; i < dim; i++) x[i] = x[i] / m;
+}
+
+Ct client_encrypt_query(Context &cx, const double *query, const uint8_t seed[32], uint64_t nonce) {
+    const int dim = cx.prm.dim;
+    std::vector<double> qn(query, query + dim), batch(cx.slots);
+    normalize(qn.data(), dim);                                                       // receiver_diag.cpp:17
+    for (int i = 0; i < cx.slots; i += dim) std::memcpy(&batch[i], qn.data(), sizeof(double) * dim);  // :18-21
+    return client_encrypt(cx, batch.data(), 1, seed, nonce);                          // :23
+}
+
+void client_decrypt(Context &cx, const Ct &ct, double *out) {
+    if (!cx.d_sk) throw std::runtime_error("hydia: secret key not loaded");
+    ensure_embedding_tables(cx);
+    const int N = cx.N, Nh = cx.slots, X = ct.X, nu = ct.nl < 2 ? ct.nl : 2;
+    u64 *t = cx.pool.get(sizeof(u64) * (size_t)X * nu * N);
+    hc::dec_dot(cx.stream, cx.d_mod, N, ct.npoly, ct.nl, ct.d, cx.d_sk, t, nu, X);
+    const LimbSel s = cx.sel_q(nu);
+    cx.ntt_inv(t, t, (size_t)nu * N, (size_t)nu * N, X, s, cx.scale_ninv(s));
+    double2 *work = (double2 *)cx.pool.get(sizeof(double2) * (size_t)X * Nh);
+    double *d_out = (double *)cx.pool.get(sizeof(double) * (size_t)X * Nh);
+    const u64 q0inv = cx.nQ >= 2 ? invmod_u64(cx.q[0] % cx.q[1], cx.q[1]) : 0;
+    hc::decode(cx.stream, cx.d_mod, t, nu, N, X, ct.scale, q0inv, work, d_out, cx.d_rot_group, (const double2 *)cx.d_ksi);
+    HIP_CHECK(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)X * Nh, hipMemcpyDeviceToHost, cx.stream));
+    cx.sync();
+    cx.pool.put((u64 *)d_out);
+    cx.pool.put((u64 *)work);
+    cx.pool.put(t);
+}
+
+#define HY_DB_NONCE_BASE (1ull << 36)
+// DiagonalEnroller::serializeDB: normalise IN PLACE (enroller_diag.cpp:32-35), then per group of `slots` rows: pack the
+// generalised diagonals (:37-45) and encrypt the vector_dim slot vectors (:48-52) into the resident HBM layout.
+void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]) {
+    const int dim = cx.prm.dim, Nh = cx.slots;
+    for (long long v = 0; v < (long long)n; v++) normalize(db + (size_t)v * dim, dim);
+    const ChaChaKey key = make_key(seed);
+    const size_t G = cx.db_cts / dim, ct_elems = (size_t)2 * cx.nQ * cx.N;
+    double *d_rows = (double *)cx.pool.get(sizeof(double) * (size_t)Nh * dim);
+    double *d_slots = (double *)cx.pool.get(sizeof(double) * (size_t)dim * Nh);
+    for (size_t g = 0; g < G; g++) {
+        const size_t first = g * (size_t)Nh;
+        const size_t rows = n > first ? std::min((size_t)Nh, n - first) : 0;
+        if (rows)
+            HIP_CHECK(hipMemcpyAsync(d_rows, db + first * dim, sizeof(double) * rows * dim, hipMemcpyHostToDevice, cx.stream));
+        hc::diag_pack(cx.stream, d_rows, (long long)rows, dim, Nh, d_slots);
+        encrypt_device(cx, d_slots, dim, key, HY_DB_NONCE_BASE + g * dim, cx.d_db + g * dim * ct_elems);
+    }
+    cx.sync();
+    cx.pool.put((u64 *)d_slots);
+    cx.pool.put((u64 *)d_rows);
+}
+
 }  // namespace hydia

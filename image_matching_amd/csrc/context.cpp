@@ -286,7 +286,7 @@ Context::~Context() {
         for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
             if (p) (void)hipFree(p);
     for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_rotptrs,
-                    (void *)d_rotgalois, (void *)d_sk, (void *)d_pk, (void *)d_db})
+                    (void *)d_rotgalois, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
 }

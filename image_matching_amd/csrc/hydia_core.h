@@ -106,6 +106,8 @@ struct Context : HostParams {
     u64 *eval_key_storage(int rot);    // allocates (or returns) the HBM buffer of key `rot`
     u64 *d_sk = nullptr;               // [nT][N] (receiver side only)
     u64 *d_pk = nullptr;               // [2][nQ][N]
+    unsigned *d_rot_group = nullptr;   // canonical embedding: 5^j mod 2N
+    double *d_ksi = nullptr;           // (cos, sin)(2 pi k / 2N), k <= 2N
 
     // encrypted database resident in HBM: [G*dim][2][nQ][N]
     u64 *d_db = nullptr;

@@ -78,6 +78,7 @@ def load_library():
         "hydia_ct_shape": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(dbl)]),
         "hydia_ct_device_ptr": (i32, [vp, pp, C.POINTER(sz)]),
         "hydia_ct_from_device": (i32, [vp, vp, u32, u32, u32, dbl, pp]),
+        "hydia_ct_copy_to_device": (i32, [vp, vp, vp]),
         "hydia_ct_free": (None, [vp]),
         "hydia_encrypt_query": (i32, [vp, vp, vp, u64, pp]),
         "hydia_encrypt": (i32, [vp, vp, u32, vp, u64, pp]),
@@ -186,6 +187,9 @@ class Ciphertext:
         out = np.zeros((c, p, l, self.cc.N), dtype=np.uint64)
         _chk(self.cc.L.hydia_ct_export(self.cc.h, self.h, _p(out)))
         return out
+
+    def copy_to_device(self, dev_ptr):
+        _chk(self.cc.L.hydia_ct_copy_to_device(self.cc.h, self.h, C.c_void_p(dev_ptr)))
 
     def device_ptr(self):
         ptr, n = C.c_void_p(), C.c_size_t()

@@ -11,8 +11,8 @@
  *   ciphertext  = uint64 residues, limb-major [poly][limb][N], EVALUATION form in bit-reversed order
  *                 (out[j] = a(psi^(2*bitrev(j)+1)) mod q_limb), limb j <-> modulus j of hydia_get_moduli();
  *                 what OpenFHE exposes as ct->GetElements()[p].GetElementAtIndex(j).GetValues() after
- *                 SetFormat(EVALUATION) when the moduli/roots agree (otherwise cross in COEFFICIENT form via
- *                 hydia_ct_import_coeff).
+ *                 SetFormat(EVALUATION) when the moduli/roots agree (otherwise cross in COEFFICIENT form and
+ *                 convert with hydia_ntt — INTEGRATION.md).
  *   eval key    = [digit][2][limb over Q then P][N] residues, poly 0 = b, poly 1 = a (hybrid key switching, dnum digits)
  *   slots       = IEEE doubles
  * All functions return 0 on success and a negative hydia_status otherwise; hydia_last_error() has the message
@@ -76,7 +76,7 @@ int hydia_memory_stats(hydia_ctx *ctx, uint64_t *pool_live, uint64_t *pool_cache
 /* ---- keys: cc->KeyGen / EvalMultKeyGen / EvalRotateKeyGen (src/main.cpp:184-206) ---- */
 /* generate sk, pk, relin key and rotation keys {1..dim-1} u {dim, 2dim, .., slots/2} on the GPU from a 32-byte seed */
 int hydia_keygen(hydia_ctx *ctx, const uint8_t seed[32]);
-/* or import keys produced elsewhere (the reference's serial/*.bin contents after unmarshalling):
+/* or import keys produced elsewhere (the reference's serial/{multkey,rotkey}.bin contents after unmarshalling):
  * rot = 0 is the relinearisation key, rot >= 1 the key of EvalRotate(., rot); data [dnum][2][n_q+n_p][N] */
 int hydia_import_eval_key(hydia_ctx *ctx, int rot, const uint64_t *data);
 int hydia_export_eval_key(hydia_ctx *ctx, int rot, uint64_t *data);
@@ -96,6 +96,8 @@ int hydia_ct_export(hydia_ctx *ctx, const hydia_ct *ct, uint64_t *data);
 int hydia_ct_shape(const hydia_ct *ct, uint32_t *count, uint32_t *n_polys, uint32_t *n_limbs, double *scale);
 /* raw HBM address of the batch (for RCCL gathers through torch.distributed; layout [count][poly][limb][N]) */
 int hydia_ct_device_ptr(const hydia_ct *ct, void **ptr, size_t *bytes);
+/* device-to-device copy of the whole batch into caller-owned HBM (e.g. a torch tensor used as RCCL send buffer) */
+int hydia_ct_copy_to_device(hydia_ctx *ctx, const hydia_ct *ct, void *dev_dst);
 int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
                          double scale, hydia_ct **out); /* copies */
 void hydia_ct_free(hydia_ct *ct);
@@ -120,8 +122,7 @@ int hydia_decrypt_index(hydia_ctx *ctx, const hydia_ct *cts, size_t *out, size_t
 size_t hydia_db_num_cts(const hydia_ctx *ctx, size_t n_vectors);
 /* DiagonalEnroller::serializeDB, src/enroller/enroller_diag.cpp:12-53: normalises db IN PLACE (like the reference),
  * diagonalises, encodes and encrypts straight into the HBM-resident layout (no serial/db_diagonal files).
- * first_vector/total_vectors select the row-block shard this GPU owns: rows [first_vector, first_vector+n) of a
- * total_vectors database (pass 0 / n for a single GPU). */
+ * For a multi-GPU database each rank enrols its own contiguous range of 16384-vector blocks (multi-GPU). */
 int hydia_db_enroll(hydia_ctx *ctx, double *db /* n x vector_dim row-major */, size_t n, const uint8_t seed[32]);
 /* or load ciphertexts produced elsewhere: t = block*vector_dim + diagonal, i.e. serial/db_diagonal/index<t>.bin
  * (src/enroller/enroller_diag.cpp:161; read back at src/sender/sender_diag.cpp:87-91) */

@@ -1,0 +1,229 @@
+// include/hydia_roles.hpp — the reference's C++ role surface for approach 5, over the C-ABI of hydia.h.
+//
+// Same class and method names as /root/reference/include/{sender,sender_diag,receiver,receiver_hers,receiver_diag,
+// enroller_diag}.h so that src/main.cpp's case 5 (:245-247, :324-327, :333-374) reads unchanged; the OpenFHE handle
+// types are replaced by thin handles onto HBM-resident objects:
+//     CryptoContext<DCRTPoly> + PublicKey + PrivateKey  ->  hydia::CryptoContext (context + keys + resident database)
+//     Ciphertext<DCRTPoly>                               ->  hydia::Ciphertext   (one element of a device batch)
+// Error behaviour mirrors the reference: a message on cerr and carry on (src/sender/sender_diag.cpp:89-91); the
+// status code of the last failing call is kept in CryptoContext::last_status for callers that want to assert.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hydia.h"
+
+namespace hydia {
+
+const double MATCH_THRESHOLD = 0.44;  // include/config.h:9
+const size_t COMP_DEPTH = 10;         // include/config.h:14
+const size_t VECTOR_DIM = 512;        // include/config.h:30
+
+class CryptoContextImpl {
+  public:
+    hydia_ctx *h = nullptr;
+    hydia_info info{};
+    int last_status = 0;
+    explicit CryptoContextImpl(const hydia_params &p, int device = 0) {
+        last_status = hydia_ctx_create(&p, device, &h);
+        if (last_status != 0) {
+            std::cerr << "Error: " << hydia_last_error() << std::endl;
+            h = nullptr;
+            return;
+        }
+        hydia_get_info(h, &info);
+    }
+    ~CryptoContextImpl() { hydia_ctx_destroy(h); }
+    CryptoContextImpl(const CryptoContextImpl &) = delete;
+    CryptoContextImpl &operator=(const CryptoContextImpl &) = delete;
+    bool check(int code, const char *what) {
+        if (code != 0) {
+            last_status = code;
+            std::cerr << "Error: " << what << ": " << hydia_last_error() << std::endl;
+        }
+        return code == 0;
+    }
+    size_t GetRingDimension() const { return info.n; }
+    size_t GetBatchSize() const { return info.slots; }
+    // cc->KeyGen(); EvalMultKeyGen; EvalSumKeyGen; EvalRotateKeyGen (src/main.cpp:184-206) in one call
+    bool KeyGen(const uint8_t seed[32]) { return check(hydia_keygen(h, seed), "key generation"); }
+};
+using CryptoContext = std::shared_ptr<CryptoContextImpl>;
+
+inline CryptoContext GenCryptoContext(size_t multDepth = 11, uint32_t scalingModSize = 45, uint32_t vectorDim = 512,
+                                      uint32_t logN = 15, int device = 0) {
+    hydia_params p;
+    hydia_default_params(&p);
+    p.mult_depth = (uint32_t)multDepth;
+    p.scale_bits = scalingModSize;
+    p.vector_dim = vectorDim;
+    p.log_n = logN;
+    return std::make_shared<CryptoContextImpl>(p, device);
+}
+
+// one ciphertext = (shared device batch, index inside it)
+struct CtBatch {
+    CryptoContext cc;
+    hydia_ct *h = nullptr;
+    CtBatch(CryptoContext c, hydia_ct *p) : cc(std::move(c)), h(p) {}
+    ~CtBatch() { hydia_ct_free(h); }
+    uint32_t count() const {
+        uint32_t c = 0;
+        if (h) hydia_ct_shape(h, &c, nullptr, nullptr, nullptr);
+        return c;
+    }
+};
+struct Ciphertext {
+    std::shared_ptr<CtBatch> batch;
+    uint32_t index = 0;
+    explicit operator bool() const { return batch && batch->h; }
+};
+inline std::vector<Ciphertext> split_batch(const CryptoContext &cc, hydia_ct *h) {
+    std::vector<Ciphertext> v;
+    if (!h) return v;
+    auto b = std::make_shared<CtBatch>(cc, h);
+    for (uint32_t i = 0; i < b->count(); i++) v.push_back(Ciphertext{b, i});
+    return v;
+}
+
+namespace OpenFHEWrapper {
+// src/openFHE_wrapper.cpp:6-44
+inline size_t computeRequiredDepth(size_t approach) { return hydia_compute_required_depth(approach); }
+// src/openFHE_wrapper.cpp:81-85 (whole batch the ciphertext belongs to; returns the slots of ct.index)
+inline std::vector<double> decryptToVector(CryptoContext cc, Ciphertext ctxt) {
+    std::vector<double> all((size_t)ctxt.batch->count() * cc->info.slots);
+    cc->check(hydia_decrypt(cc->h, ctxt.batch->h, all.data()), "decrypt");
+    return std::vector<double>(all.begin() + (size_t)ctxt.index * cc->info.slots,
+                               all.begin() + (size_t)(ctxt.index + 1) * cc->info.slots);
+}
+}  // namespace OpenFHEWrapper
+
+// ---- include/sender.h:19-43
+class Sender {
+  public:
+    Sender(CryptoContext ccParam, size_t vectorParam) : cc(std::move(ccParam)), numVectors(vectorParam) {}
+    virtual ~Sender() = default;
+    virtual std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) = 0;
+    virtual Ciphertext membershipScenario(std::vector<Ciphertext> &queryCipher) = 0;
+    virtual std::vector<Ciphertext> indexScenario(std::vector<Ciphertext> &queryCipher) = 0;
+
+  protected:
+    CryptoContext cc;
+    size_t numVectors;
+};
+// ---- include/sender_diag.h:5-28 (HersSender's own bodies are approach 4, out of scope)
+class DiagonalSender : public Sender {
+  public:
+    DiagonalSender(CryptoContext ccParam, size_t vectorParam) : Sender(std::move(ccParam), vectorParam) {}
+    std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) override {
+        hydia_ct *out = nullptr;
+        if (!query_ok(queryCipher) || !cc->check(hydia_compute_similarity(cc->h, queryCipher[0].batch->h, &out), "computeSimilarity"))
+            return {};
+        return split_batch(cc, out);
+    }
+    Ciphertext membershipScenario(std::vector<Ciphertext> &queryCipher) override {
+        hydia_ct *out = nullptr;
+        if (!query_ok(queryCipher) || !cc->check(hydia_membership_scenario(cc->h, queryCipher[0].batch->h, &out), "membershipScenario"))
+            return Ciphertext{};
+        return split_batch(cc, out)[0];
+    }
+    std::vector<Ciphertext> indexScenario(std::vector<Ciphertext> &queryCipher) override {
+        hydia_ct *out = nullptr;
+        if (!query_ok(queryCipher) || !cc->check(hydia_index_scenario(cc->h, queryCipher[0].batch->h, &out), "indexScenario"))
+            return {};
+        return split_batch(cc, out);
+    }
+
+  private:
+    bool query_ok(std::vector<Ciphertext> &q) {
+        if (q.empty() || !q[0]) {
+            std::cerr << "Error: empty query ciphertext" << std::endl;
+            return false;
+        }
+        return true;
+    }
+};
+
+// ---- include/receiver.h:17-43, include/receiver_hers.h, include/receiver_diag.h
+class Receiver {
+  public:
+    Receiver(CryptoContext ccParam, size_t vectorParam) : cc(std::move(ccParam)), numVectors(vectorParam) {}
+    virtual ~Receiver() = default;
+    virtual std::vector<Ciphertext> encryptQuery(std::vector<double> query) = 0;
+    virtual bool decryptMembership(Ciphertext &membershipCipher) = 0;
+    virtual std::vector<size_t> decryptIndex(std::vector<Ciphertext> &indexCipher) = 0;
+
+  protected:
+    CryptoContext cc;
+    size_t numVectors;
+};
+class HersReceiver : public Receiver {
+  public:
+    using Receiver::Receiver;
+    // src/receiver/receiver_hers.cpp:26-35
+    bool decryptMembership(Ciphertext &membershipCipher) override {
+        if (!membershipCipher) return false;
+        return OpenFHEWrapper::decryptToVector(cc, membershipCipher)[0] >= 1.0;
+    }
+    // src/receiver/receiver_hers.cpp:37-54
+    std::vector<size_t> decryptIndex(std::vector<Ciphertext> &indexCipher) override {
+        size_t batchSize = cc->GetBatchSize();
+        std::vector<size_t> outputValues;
+        for (size_t i = 0; i < indexCipher.size(); i++) {
+            if (!indexCipher[i]) continue;
+            std::vector<double> indexValues = OpenFHEWrapper::decryptToVector(cc, indexCipher[i]);
+            for (size_t j = 0; j < batchSize; j++)
+                if (indexValues[j] >= 1.0) outputValues.push_back(j + (i * batchSize));
+        }
+        return outputValues;
+    }
+};
+class DiagonalReceiver : public HersReceiver {
+  public:
+    DiagonalReceiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
+        : HersReceiver(std::move(ccParam), vectorParam) {
+        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0xA5 ^ i);
+    }
+    // src/receiver/receiver_diag.cpp:13-26
+    std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
+        hydia_ct *out = nullptr;
+        if (query.size() < cc->info.vector_dim) query.resize(cc->info.vector_dim, 0.0);
+        if (!cc->check(hydia_encrypt_query(cc->h, query.data(), seed, ++nonce, &out), "encryptQuery")) return {};
+        return split_batch(cc, out);
+    }
+
+  private:
+    uint8_t seed[32];
+    uint64_t nonce = 0;
+};
+
+// ---- include/enroller_diag.h:7-27
+class DiagonalEnroller {
+  public:
+    DiagonalEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
+        : cc(std::move(ccParam)), numVectors(vectorParam) {
+        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0x5A ^ i);
+    }
+    // src/enroller/enroller_diag.cpp:12-53 — normalises `database` in place; ciphertexts go to HBM, not to
+    // serial/db_diagonal/index<t>.bin
+    void serializeDB(std::vector<std::vector<double>> &database) {
+        const size_t dim = cc->info.vector_dim;
+        std::vector<double> flat(numVectors * dim, 0.0);
+        for (size_t i = 0; i < numVectors && i < database.size(); i++)
+            for (size_t j = 0; j < dim && j < database[i].size(); j++) flat[i * dim + j] = database[i][j];
+        if (!cc->check(hydia_db_enroll(cc->h, flat.data(), numVectors, seed), "serializeDB")) return;
+        for (size_t i = 0; i < numVectors && i < database.size(); i++)
+            for (size_t j = 0; j < dim && j < database[i].size(); j++) database[i][j] = flat[i * dim + j];
+    }
+
+  protected:
+    CryptoContext cc;
+    size_t numVectors;
+    uint8_t seed[32];
+};
+
+}  // namespace hydia

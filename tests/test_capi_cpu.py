@@ -1,0 +1,83 @@
+"""CPU-only checks of the product boundary: libhydia.so loads, exports every symbol include/hydia.h declares, derives
+the same RNS parameters as the oracle, and refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def im():
+    import image_matching_amd as im
+    if not os.path.exists(im.lib_path()):
+        from image_matching_amd.hydia import build_library
+        build_library()
+    return im
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hydia.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hydia_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(im):
+    L = im.load_library()
+    names = declared_symbols()
+    assert len(names) >= 50
+    raw = ctypes.CDLL(im.lib_path())
+    for n in names:
+        assert hasattr(raw, n), "include/hydia.h declares %s but libhydia.so does not export it" % n
+    # and the Python host layer binds all of them
+    assert set(names) <= set(L._hydia_symbols), sorted(set(names) - set(L._hydia_symbols))
+
+
+def test_parameter_derivation_matches_oracle(im):
+    for kw, okw in ((dict(), dict()), (dict(log_n=11, vector_dim=64), dict(log_n=11, dim=64)),
+                    (dict(log_n=12, mult_depth=5, dnum=2, vector_dim=128), dict(log_n=12, depth=5, dnum=2, dim=128)),
+                    (dict(log_n=13, mult_depth=3, dnum=4, vector_dim=512), dict(log_n=13, depth=3, dnum=4, dim=512))):
+        info, moduli, roots = im.describe_params(im.default_params(**kw))
+        P = O.Params(**okw)
+        assert (info["n"], info["slots"], info["n_q"], info["n_p"], info["alpha"]) == (P.N, P.slots, P.nQ, P.nP, P.alpha)
+        assert np.array_equal(moduli, P.moduli) and np.array_equal(roots, P.roots)
+        P.close()
+
+
+def test_required_depth_table(im):
+    # src/openFHE_wrapper.cpp:6-44 with COMP_DEPTH 10, ALPHA_DEPTH 2
+    assert [im.compute_required_depth(a) for a in (1, 2, 3, 4, 5)] == [13, 18, 12, 11, 11]
+    assert im.default_params().mult_depth == 11
+
+
+def test_bad_parameters_are_rejected(im):
+    with pytest.raises(im.HydiaError):
+        im.describe_params(im.default_params(log_n=9))
+    with pytest.raises(im.HydiaError):
+        im.describe_params(im.default_params(vector_dim=500))
+
+
+def test_no_gpu_means_loud_failure(im):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(im.HydiaError) as e:
+        im.Context()
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """image_matching_amd/ and bench.py's hot path must not import or link oracle/ (bench.py may, in cpu_baseline only)."""
+    pkg = os.path.join(ROOT, "image_matching_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                text = open(os.path.join(d, f)).read()
+                assert "oracle_lib" not in text and "liboracle" not in text and "hydia_oracle" not in text, f
+    import subprocess
+    ldd = subprocess.run(["ldd", os.path.join(pkg, "libhydia.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
