@@ -50,9 +50,11 @@ static void fill_info(const HostParams &h, hydia_info *o) {
     o->log_n = h.prm.logN; o->n = h.N; o->slots = h.slots; o->n_q = h.nQ; o->n_p = h.nP; o->dnum = h.prm.dnum;
     o->alpha = h.alpha; o->vector_dim = h.prm.dim; o->delta = h.delta;
 }
+// handles that cross the C-ABI are always compact ([count][poly][limb][N], nl == lstride) and owning
 static hydia_ct *wrap(Ct &&c) {
     hydia_ct *h = new hydia_ct;
-    h->c = std::move(c);
+    if (c.view || !c.compact()) h->c = c.ctx->clone(c);
+    else h->c = std::move(c);
     return h;
 }
 
@@ -472,7 +474,10 @@ int hydia_eval_add(hydia_ctx *ctx, hydia_ct *a, const hydia_ct *b) {
 int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs) {
     API_BEGIN
     REQUIRE(ctx && ct && n_limbs >= 1, "bad argument");
-    ctx->cx.drop_to(ct->c, (int)n_limbs);
+    if ((int)n_limbs < ct->c.nl) {
+        Ct v = ct->c.alias((int)n_limbs);
+        ct->c = ctx->cx.clone(v);
+    }
     return HYDIA_OK;
     API_END
 }

@@ -36,9 +36,12 @@ static void ensure_embedding_tables(Context &cx) {
     }
     std::vector<double> ksi(2 * (size_t)(M + 1));
     for (int k = 0; k <= M; k++) {
+        // explicit glibc sincos(): the specification's table (a compiler may or may not fuse sin()+cos() itself)
         const double ang = 2.0 * M_PI * (double)k / (double)M;
-        ksi[2 * (size_t)k] = std::cos(ang);
-        ksi[2 * (size_t)k + 1] = std::sin(ang);
+        double sn, cs;
+        ::sincos(ang, &sn, &cs);
+        ksi[2 * (size_t)k] = cs;
+        ksi[2 * (size_t)k + 1] = sn;
     }
     HIP_CHECK(hipMalloc((void **)&cx.d_rot_group, sizeof(unsigned) * rg.size()));
     HIP_CHECK(hipMalloc((void **)&cx.d_ksi, sizeof(double) * ksi.size()));
@@ -170,7 +173,7 @@ void client_decrypt(Context &cx, const Ct &ct, double *out) {
     ensure_embedding_tables(cx);
     const int N = cx.N, Nh = cx.slots, X = ct.X, nu = ct.nl < 2 ? ct.nl : 2;
     u64 *t = cx.pool.get(sizeof(u64) * (size_t)X * nu * N);
-    hc::dec_dot(cx.stream, cx.d_mod, N, ct.npoly, ct.nl, ct.d, cx.d_sk, t, nu, X);
+    hc::dec_dot(cx.stream, cx.d_mod, N, ct.npoly, ct.lstride, ct.d, cx.d_sk, t, nu, X);
     const LimbSel s = cx.sel_q(nu);
     cx.ntt_inv(t, t, (size_t)nu * N, (size_t)nu * N, X, s, cx.scale_ninv(s));
     double2 *work = (double2 *)cx.pool.get(sizeof(double2) * (size_t)X * Nh);

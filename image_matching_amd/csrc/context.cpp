@@ -6,6 +6,7 @@
 // framework's own deterministic specification (DESIGN.md §"RNS parameters"); tests check it against the oracle.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "hydia_core.h"
@@ -139,13 +140,14 @@ void Pool::trim() {
 }
 
 // ------------------------------------------------------------------ Ct
-Ct::Ct(Context *c, int X_, int npoly_, int nl_, double scale_) : ctx(c), X(X_), npoly(npoly_), nl(nl_), scale(scale_) {
+Ct::Ct(Context *c, int X_, int npoly_, int nl_, double scale_)
+    : ctx(c), X(X_), npoly(npoly_), nl(nl_), lstride(nl_), scale(scale_) {
     d = c->pool.get(bytes());
 }
 Ct &Ct::operator=(Ct &&o) noexcept {
     if (this != &o) {
         if (d && !view && ctx) ctx->pool.put(d);
-        ctx = o.ctx; d = o.d; X = o.X; npoly = o.npoly; nl = o.nl; scale = o.scale; view = o.view;
+        ctx = o.ctx; d = o.d; X = o.X; npoly = o.npoly; nl = o.nl; lstride = o.lstride; scale = o.scale; view = o.view;
         o.d = nullptr;
     }
     return *this;
@@ -153,7 +155,13 @@ Ct &Ct::operator=(Ct &&o) noexcept {
 Ct::~Ct() {
     if (d && !view && ctx) ctx->pool.put(d);
 }
-size_t Ct::ct_elems() const { return (size_t)npoly * nl * ctx->N; }
+size_t Ct::poly_elems() const { return (size_t)lstride * ctx->N; }
+Ct Ct::alias(int nl_) const {
+    Ct v;
+    v.ctx = ctx; v.d = d; v.X = X; v.npoly = npoly; v.nl = nl_ < nl ? nl_ : nl; v.lstride = lstride; v.scale = scale;
+    v.view = true;
+    return v;
+}
 
 // ------------------------------------------------------------------ context
 HostParams::HostParams(const Params &p) : prm(p) {
@@ -266,7 +274,21 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     HIP_CHECK(hipMemcpy(d_tw_sh, tws.data(), tb, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_itw, itw.data(), tb, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_itw_sh, itws.data(), tb, hipMemcpyHostToDevice));
-    tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod};
+    {   // interleaved (w, w') pairs for the register-radix kernels
+        std::vector<u64> pr(2 * (size_t)nT * N), ipr(2 * (size_t)nT * N);
+        for (size_t i = 0; i < (size_t)nT * N; i++) {
+            pr[2 * i] = tw[i];
+            pr[2 * i + 1] = tws[i];
+            ipr[2 * i] = itw[i];
+            ipr[2 * i + 1] = itws[i];
+        }
+        HIP_CHECK(hipMalloc((void **)&d_twp, 2 * tb));
+        HIP_CHECK(hipMalloc((void **)&d_itwp, 2 * tb));
+        HIP_CHECK(hipMemcpy(d_twp, pr.data(), 2 * tb, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_itwp, ipr.data(), 2 * tb, hipMemcpyHostToDevice));
+    }
+    tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod, (const ulonglong2 *)d_twp, (const ulonglong2 *)d_itwp};
+    if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     HIP_CHECK(hipMalloc((void **)&d_rotptrs, sizeof(u64 *) * (size_t)p.dim));
     HIP_CHECK(hipMalloc((void **)&d_rotgalois, sizeof(unsigned) * (size_t)p.dim));
 
@@ -285,7 +307,8 @@ Context::~Context() {
     for (auto &kv : rot_keys)
         for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
             if (p) (void)hipFree(p);
-    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_rotptrs,
+    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp,
+                    (void *)d_rotptrs,
                     (void *)d_rotgalois, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);

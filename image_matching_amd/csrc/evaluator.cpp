@@ -73,8 +73,8 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
 // <digits, key> over Q_l u P, then ModDown by P; optionally adds `addend` and applies the evaluation-form
 // automorphism (EvalFastRotation's tail).  out: [X][2][nl][N].
 void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
-                       const u64 *addend, size_t add_x_stride, int add_polys, const unsigned *d_galois, int same_galois,
-                       u64 *out) {
+                       const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys,
+                       const unsigned *d_galois, int same_galois, u64 *out) {
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
@@ -96,7 +96,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
     ntt_fwd(conv, (size_t)nl * N, X * 2, qsel);
     std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
-    hk::moddown_combine(stream, d_mod, prm.logN, acc, nE, conv, addend, add_x_stride, add_polys, out, X, nl,
+    hk::moddown_combine(stream, d_mod, prm.logN, acc, nE, conv, addend, add_x_stride, add_poly_stride, add_polys, out, X, nl,
                         scale_of(qsel, pinv, false), d_galois, same_galois);
     pool.put(conv);
     pool.put(y);
@@ -124,9 +124,9 @@ void Context::relinearize(Ct &c) {
     if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
     const int nl = c.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
-    modup_digits(c.d + (size_t)2 * nl * N, (size_t)3 * nl * N, X, nl, dig);
+    modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, c.scale);
-    ks_apply(dig, (size_t)nd * nE * N, X, nl, relin_key.d_cell, 1, c.d, (size_t)3 * nl * N, 2, nullptr, 0, out.d);
+    ks_apply(dig, (size_t)nd * nE * N, X, nl, relin_key.d_cell, 1, c.d, c.ct_elems(), c.poly_elems(), 2, nullptr, 0, out.d);
     pool.put(dig);
     c = std::move(out);
 }
@@ -136,28 +136,25 @@ void Context::rescale(Ct &c) {
     if (nl < 2) throw std::runtime_error("hydia: rescale with one limb left");
     u64 *t = pool.get((size_t)XP * N * sizeof(u64));
     const LimbSel last = sel_range(l, l + 1);
-    ntt_inv(c.d + (size_t)l * N, t, (size_t)nl * N, (size_t)N, XP, last, scale_ninv(last));
+    ntt_inv(c.d + (size_t)l * N, t, c.poly_elems(), (size_t)N, XP, last, scale_ninv(last));
     u64 *tmp = pool.get((size_t)XP * l * N * sizeof(u64));
     hk::rescale_spread(stream, d_mod, N, t, tmp, XP, l);
     const LimbSel qsel = sel_q(l);
     ntt_fwd(tmp, (size_t)l * N, XP, qsel);
     Ct out(this, c.X, c.npoly, l, c.scale / (double)q[l]);
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
-    hk::rescale_combine(stream, d_mod, N, c.d, tmp, out.d, XP, l, scale_of(qsel, qi, false));
+    hk::rescale_combine(stream, d_mod, N, c.d, tmp, out.d, XP, l, scale_of(qsel, qi, false), c.lstride);
     pool.put(tmp);
     pool.put(t);
     c = std::move(out);
 }
 Ct Context::clone(const Ct &a) {
     Ct o(this, a.X, a.npoly, a.nl, a.scale);
-    HIP_CHECK(hipMemcpyAsync(o.d, a.d, a.bytes(), hipMemcpyDeviceToDevice, stream));
+    hk::copy_limbs(stream, N, a.d, o.d, a.poly_elems(), o.poly_elems(), a.X * a.npoly, a.nl);
     return o;
 }
 void Context::drop_to(Ct &a, int nl) {
-    if (nl >= a.nl) return;
-    Ct o(this, a.X, a.npoly, nl, a.scale);
-    hk::copy_limbs(stream, N, a.d, o.d, (size_t)a.nl * N, (size_t)nl * N, a.X * a.npoly, nl);
-    a = std::move(o);
+    if (nl < a.nl) a.nl = nl;
 }
 static void check_same(const Ct &a, const Ct &b, const char *what) {
     if (a.X != b.X || a.npoly != b.npoly || a.nl != b.nl)
@@ -165,11 +162,11 @@ static void check_same(const Ct &a, const Ct &b, const char *what) {
 }
 void Context::add_inplace(Ct &a, const Ct &b) {
     check_same(a, b, "add");
-    hk::add(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl));
+    hk::add(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride, b.lstride, a.lstride);
 }
 void Context::sub_inplace(Ct &a, const Ct &b) {
     check_same(a, b, "sub");
-    hk::sub(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl));
+    hk::sub(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride, b.lstride, a.lstride);
 }
 // EvalAddInPlace(ct, double) (openFHE_wrapper.cpp:182)
 void Context::add_const(Ct &a, double c) {
@@ -186,31 +183,20 @@ Ct Context::mul_const(const Ct &a, double c, double const_scale) {
         sc.s_sh[j] = shoup_h(sc.s[j], q[j]);
     }
     Ct o(this, a.X, a.npoly, a.nl, a.scale * const_scale);
-    hk::mul_scalar(stream, d_mod, N, a.d, o.d, a.X * a.npoly, s, sc);
+    hk::mul_scalar(stream, d_mod, N, a.d, o.d, a.X * a.npoly, s, sc, a.lstride, o.lstride);
     return o;
 }
 // EvalMultNoRelin (sender_diag.cpp:93)
 Ct Context::mult_norelin(const Ct &a, const Ct &b) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
     Ct o(this, a.X, 3, a.nl, a.scale * b.scale);
-    hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl);
+    hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl, a.lstride, b.lstride);
     return o;
 }
 Ct Context::mult(const Ct &a, const Ct &b) {
     const int nl = std::min(a.nl, b.nl);
-    Ct x, y;
-    const Ct *pa = &a, *pb = &b;
-    if (a.nl != nl) {
-        x = clone(a);
-        drop_to(x, nl);
-        pa = &x;
-    }
-    if (b.nl != nl) {
-        y = clone(b);
-        drop_to(y, nl);
-        pb = &y;
-    }
-    Ct o = mult_norelin(*pa, *pb);
+    Ct x = a.alias(nl), y = b.alias(nl);
+    Ct o = mult_norelin(x, y);
     relinearize(o);
     rescale(o);
     return o;
@@ -221,9 +207,10 @@ Ct Context::rotate(const Ct &a, int rot) {
     if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(rot) + " not loaded");
     const int nl = a.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = a.X;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
-    modup_digits(a.d + (size_t)nl * N, (size_t)2 * nl * N, X, nl, dig);
+    modup_digits(a.d + a.poly_elems(), a.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, a.scale);
-    ks_apply(dig, (size_t)nd * nE * N, X, nl, it->second.d_cell, 1, a.d, (size_t)2 * nl * N, 1, it->second.d_gal, 1, out.d);
+    ks_apply(dig, (size_t)nd * nE * N, X, nl, it->second.d_cell, 1, a.d, a.ct_elems(), a.poly_elems(), 1, it->second.d_gal, 1,
+             out.d);
     pool.put(dig);
     return out;
 }
@@ -232,7 +219,7 @@ Ct Context::rotate(const Ct &a, int rot) {
 // loop A (sender_diag.cpp:20-26): ONE ModUp of the query's c1, then dim-1 hoisted rotations as one batched
 // inner-product + ModDown + automorphism sequence.  Output: rot[0] = q, rot[i] = Rot_i(q).
 Ct Context::rotate_query(const Ct &qc) {
-    if (qc.X != 1 || qc.npoly != 2) throw std::runtime_error("hydia: query must be one 2-component ciphertext");
+    if (qc.X != 1 || qc.npoly != 2 || !qc.compact()) throw std::runtime_error("hydia: query must be one 2-component ciphertext");
     build_rotptrs();
     const int nl = qc.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, dim = prm.dim;
     u64 *dig = pool.get((size_t)nd * nE * N * sizeof(u64));
@@ -240,7 +227,7 @@ Ct Context::rotate_query(const Ct &qc) {
     Ct rot(this, dim, 2, nl, qc.scale);
     HIP_CHECK(hipMemcpyAsync(rot.d, qc.d, qc.bytes(), hipMemcpyDeviceToDevice, stream));
     if (dim > 1)
-        ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, 1, d_rotgalois + 1, 0, rot.d + rot.ct_elems());
+        ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + 1, 0, rot.d + rot.ct_elems());
     pool.put(dig);
     return rot;
 }
@@ -253,7 +240,7 @@ Ct Context::similarity(const Ct &qc) {
     Ct rot = rotate_query(qc);
     Ct acc(this, G, 3, nQ, qc.scale * delta);
     timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ);
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp);
     timer_end("hydia_tensor");
     relinearize(acc);
     rescale(acc);
@@ -270,21 +257,13 @@ struct Cheb {
 // 2ab - c (c == nullptr: the constant 1)
 Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
     const int nl = std::min(a.nl, b.nl);
-    Ct x = cx->clone(a), y;
-    cx->drop_to(x, nl);
-    const Ct *pb = &x;
-    if (&a != &b) {
-        y = cx->clone(b);
-        cx->drop_to(y, nl);
-        pb = &y;
-    }
-    Ct o = cx->mult_norelin(x, *pb);
+    Ct x = a.alias(nl), y = b.alias(nl);
+    Ct o = cx->mult_norelin(x, y);
     cx->relinearize(o);
     cx->add_inplace(o, o);
     cx->rescale(o);
     if (c) {
-        Ct cc = cx->clone(*c);
-        cx->drop_to(cc, o.nl);
+        Ct cc = c->alias(o.nl);
         cx->sub_inplace(o, cc);
     } else {
         cx->add_const(o, -1.0);
@@ -306,8 +285,7 @@ Ct cheb_leaf(Cheb &ch, const double *c, int deg) {
     for (int j = 1; j <= last; j++) {
         const double cj = any ? c[j] : 0.0;
         if (cj == 0.0 && any) continue;
-        Ct t = cx->clone(ch.T[j]);
-        cx->drop_to(t, nl);
+        Ct t = ch.T[j].alias(nl);
         Ct m = cx->mul_const(t, cj, S / t.scale);
         m.scale = S;
         if (!acc.d) acc = std::move(m);
@@ -367,7 +345,7 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     Cheb ch;
     ch.cx = this;
     ch.T.resize(9);
-    ch.T[1] = clone(x);
+    ch.T[1] = x.alias(x.nl);
     const int top = std::min(degree, 8);
     if (top >= 2) ch.T[2] = cheb_step(this, ch.T[1], ch.T[1], nullptr);
     if (top >= 3) ch.T[3] = cheb_step(this, ch.T[2], ch.T[1], &ch.T[1]);
@@ -378,10 +356,7 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     if (top >= 8) ch.T[8] = cheb_step(this, ch.T[4], ch.T[4], nullptr);
     int gi = -1;
     if (degree >= 8) {
-        ch.G.emplace_back();
-        Ct &g0 = ch.G.back();
-        g0.ctx = this; g0.d = ch.T[8].d; g0.X = ch.T[8].X; g0.npoly = 2; g0.nl = ch.T[8].nl; g0.scale = ch.T[8].scale;
-        g0.view = true;
+        ch.G.push_back(ch.T[8].alias(ch.T[8].nl));
         gi = 0;
         while ((8 << (gi + 1)) <= degree) {
             Ct nx = cheb_step(this, ch.G[gi], ch.G[gi], nullptr);
@@ -396,8 +371,7 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     Ct y2 = mult(y, y), y3 = mult(y2, y), y4 = mult(y2, y2), y8 = mult(y4, y4);
     const int nl = y3.nl;
     const double S = delta * (double)q[nl - 1];
-    Ct yd = clone(y);
-    drop_to(yd, nl);
+    Ct yd = y.alias(nl);
     Ct u = mul_const(yd, F4[1], S / yd.scale), t = mul_const(y3, F4[3], S / y3.scale);
     u.scale = t.scale = S;
     add_inplace(u, t);
@@ -433,11 +407,13 @@ Ct Context::membership_scenario(const Ct &qc) {
     return sum_and_evalsum(s);
 }
 Ct Context::sum_and_evalsum(const Ct &s) {
-    Ct m(this, 1, 2, s.nl, s.scale);
-    HIP_CHECK(hipMemcpyAsync(m.d, s.d, m.bytes(), hipMemcpyDeviceToDevice, stream));
+    Ct first = s.alias(s.nl);
+    first.X = 1;
+    Ct m = clone(first);
     for (int g = 1; g < s.X; g++) {
-        Ct v;
-        v.ctx = this; v.d = s.d + (size_t)g * s.ct_elems(); v.X = 1; v.npoly = 2; v.nl = s.nl; v.scale = s.scale; v.view = true;
+        Ct v = s.alias(s.nl);
+        v.X = 1;
+        v.d = s.d + (size_t)g * s.ct_elems();
         add_inplace(m, v);
     }
     for (int r = 1; r < slots; r <<= 1) {

@@ -42,11 +42,13 @@ class Pool {
 
 struct Context;
 
-// A batch of X ciphertexts of identical shape, [X][npoly][nl][N], evaluation form, resident in HBM.
+// A batch of X ciphertexts of identical shape, [X][npoly][lstride][N] with the first nl limbs of each polynomial in
+// use, evaluation form, resident in HBM.  lstride > nl after a level drop: dropping limbs is O(1) (a view keeps the
+// allocation), every kernel that consumes ciphertexts takes the limb stride.
 struct Ct {
     Context *ctx = nullptr;
     u64 *d = nullptr;
-    int X = 0, npoly = 0, nl = 0;
+    int X = 0, npoly = 0, nl = 0, lstride = 0;
     double scale = 0;
     bool view = false;  // does not own d
     Ct() = default;
@@ -56,8 +58,11 @@ struct Ct {
     Ct(Ct &&o) noexcept { *this = std::move(o); }
     Ct &operator=(Ct &&o) noexcept;
     ~Ct();
-    size_t ct_elems() const;
-    size_t bytes() const { return ct_elems() * X * sizeof(u64); }
+    size_t poly_elems() const;                                    // lstride * N
+    size_t ct_elems() const { return (size_t)npoly * poly_elems(); }
+    size_t bytes() const { return ct_elems() * X * sizeof(u64); }  // allocated bytes
+    bool compact() const { return lstride == nl; }
+    Ct alias(int nl_) const;  // non-owning view with nl_ <= nl limbs in use
 };
 
 struct KernelTimer {
@@ -87,7 +92,7 @@ struct Context : HostParams {
 
     // device tables
     ModC *d_mod = nullptr;
-    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr;
+    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr, *d_twp = nullptr, *d_itwp = nullptr;
     NttTables tabs{};
 
     // evaluation keys resident in HBM: [dnum][2][nT][N]; each carries a one-element device cell holding its own
@@ -135,13 +140,14 @@ struct Context : HostParams {
     void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig);
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
     void ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
-                  const u64 *addend, size_t add_x_stride, int add_polys, const unsigned *d_galois, int same_galois,
-                  u64 *out);
+                  const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys, const unsigned *d_galois,
+                  int same_galois, u64 *out);
     void build_rotptrs();
     void relinearize(Ct &c);  // [X][3][nl] -> [X][2][nl]
     void rescale(Ct &c);      // drop the last limb
-    Ct clone(const Ct &a);
-    void drop_to(Ct &a, int nl);
+    Ct clone(const Ct &a);          // compact copy
+    void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
+    int tensor_bpp = 4;             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
     void add_inplace(Ct &a, const Ct &b);
     void sub_inplace(Ct &a, const Ct &b);
     void add_const(Ct &a, double c);

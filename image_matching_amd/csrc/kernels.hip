@@ -12,6 +12,8 @@
 // instruction) of one limb, so modulus constants are wave-uniform.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 DEV unsigned brev_n(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
@@ -111,31 +113,31 @@ __global__ __launch_bounds__(256) void k_ntt_contig(NttTables T, int logN, const
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise
-// grid: (N/512, X*sel.n); each thread 2 coefficients (16 B)
-#define EW_PROLOGUE                                                                         \
-    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n;                          \
-    const ModC M = mod[sel.mod[slot]];                                                      \
-    const size_t off = ((size_t)x * sel.n + slot) * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
-
+// grid: (N/512, XP*sel.n) over XP polynomials; each thread 2 coefficients (16 B).  Operands may be limb-strided views
+// (a dropped ciphertext keeps its allocation): polynomial xp of operand t starts at xp * t_ls * N.
 template <int OP>
 __global__ __launch_bounds__(256) void k_addsub(const ModC *__restrict__ mod, int N, const u64 *a, const u64 *b, u64 *o,
-                                                LimbSel sel) {  // a, b, o may alias (in-place add, doubling)
-    EW_PROLOGUE
-    const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + off);
-    const ulonglong2 vb = *reinterpret_cast<const ulonglong2 *>(b + off);
+                                                LimbSel sel, int a_ls, int b_ls, int o_ls) {  // a, b, o may alias
+    const int y = blockIdx.y, xp = y / sel.n, slot = y - xp * sel.n;
+    const u64 q = mod[sel.mod[slot]].q;
+    const size_t i = (size_t)slot * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + (size_t)xp * a_ls * N + i);
+    const ulonglong2 vb = *reinterpret_cast<const ulonglong2 *>(b + (size_t)xp * b_ls * N + i);
     ulonglong2 r;
-    r.x = OP == 0 ? addmod(va.x, vb.x, M.q) : submod(va.x, vb.x, M.q);
-    r.y = OP == 0 ? addmod(va.y, vb.y, M.q) : submod(va.y, vb.y, M.q);
-    *reinterpret_cast<ulonglong2 *>(o + off) = r;
+    r.x = OP == 0 ? addmod(va.x, vb.x, q) : submod(va.x, vb.x, q);
+    r.y = OP == 0 ? addmod(va.y, vb.y, q) : submod(va.y, vb.y, q);
+    *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * o_ls * N + i) = r;
 }
 __global__ __launch_bounds__(256) void k_mul_scalar(const ModC *__restrict__ mod, int N, const u64 *__restrict__ a,
-                                                    u64 *__restrict__ o, LimbSel sel, ScaleSel c) {
-    EW_PROLOGUE
-    const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + off);
+                                                    u64 *__restrict__ o, LimbSel sel, ScaleSel c, int a_ls, int o_ls) {
+    const int y = blockIdx.y, xp = y / sel.n, slot = y - xp * sel.n;
+    const u64 q = mod[sel.mod[slot]].q;
+    const size_t i = (size_t)slot * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + (size_t)xp * a_ls * N + i);
     ulonglong2 r;
-    r.x = mulmod_shoup(va.x, c.s[slot], c.s_sh[slot], M.q);
-    r.y = mulmod_shoup(va.y, c.s[slot], c.s_sh[slot], M.q);
-    *reinterpret_cast<ulonglong2 *>(o + off) = r;
+    r.x = mulmod_shoup(va.x, c.s[slot], c.s_sh[slot], q);
+    r.y = mulmod_shoup(va.y, c.s[slot], c.s_sh[slot], q);
+    *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * o_ls * N + i) = r;
 }
 __global__ __launch_bounds__(256) void k_add_scalar(const ModC *__restrict__ mod, int N, u64 *__restrict__ a,
                                                     size_t outer, LimbSel sel, ScaleSel c) {
@@ -154,15 +156,15 @@ __global__ __launch_bounds__(256) void k_copy_limbs(int N, const u64 *__restrict
     *reinterpret_cast<ulonglong2 *>(dst + (size_t)x * dso + (size_t)slot * N + i) =
         *reinterpret_cast<const ulonglong2 *>(src + (size_t)x * so + (size_t)slot * N + i);
 }
-// EvalMultNoRelin on X pairs: grid (N/512, nl, X)
+// EvalMultNoRelin on X pairs: grid (N/512, nl, X); inputs may be limb-strided views, output compact
 __global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ a,
-                                                const u64 *__restrict__ b, u64 *__restrict__ o, int nl) {
+                                                const u64 *__restrict__ b, u64 *__restrict__ o, int nl, int a_ls, int b_ls) {
     const int j = blockIdx.y, x = blockIdx.z;
     const ModC M = mod[j];
-    const size_t i = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
-    const size_t pa = ((size_t)x * 2 * nl + j) * N + i, ps = (size_t)nl * N;
-    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(a + pa), a1 = *reinterpret_cast<const ulonglong2 *>(a + pa + ps);
-    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(b + pa), b1 = *reinterpret_cast<const ulonglong2 *>(b + pa + ps);
+    const size_t i = (size_t)j * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t pa = (size_t)x * 2 * a_ls * N + i, pb = (size_t)x * 2 * b_ls * N + i, ps = (size_t)nl * N;
+    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(a + pa), a1 = *reinterpret_cast<const ulonglong2 *>(a + pa + (size_t)a_ls * N);
+    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(b + pb), b1 = *reinterpret_cast<const ulonglong2 *>(b + pb + (size_t)b_ls * N);
     ulonglong2 d0, d1, d2;
     d0.x = mulmod(a0.x, b0.x, M);
     d0.y = mulmod(a0.y, b0.y, M);
@@ -170,24 +172,39 @@ __global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, in
     d1.y = reduce128((u128)a0.y * b1.y + (u128)a1.y * b0.y, M);
     d2.x = mulmod(a1.x, b1.x, M);
     d2.y = mulmod(a1.y, b1.y, M);
-    const size_t po = ((size_t)x * 3 * nl + j) * N + i;
+    const size_t po = (size_t)x * 3 * ps + i;
     *reinterpret_cast<ulonglong2 *>(o + po) = d0;
     *reinterpret_cast<ulonglong2 *>(o + po + ps) = d1;
     *reinterpret_cast<ulonglong2 *>(o + po + 2 * ps) = d2;
 }
 
 // ------------------------------------------------------------------------------------------------ key switching
-// grid (N/256, nt, X)
+// grid (N/512, X): each thread reads its ns source residues ONCE (2 coefficients, 16 B loads) and produces all nt
+// targets — (ns + nt) limb-polys of traffic instead of nt*(ns + 1)
 __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
                                                       size_t yo, u64 *__restrict__ out, size_t oo, ConvTab tab,
                                                       LimbSel dsel) {
-    const int t = blockIdx.y, x = blockIdx.z;
-    if (t >= tab.skip_lo && t < tab.skip_hi) return;
-    const ModC M = mod[dsel.mod[t]];
-    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    u128 acc = 0;
-    for (int s = 0; s < tab.ns; s++) acc += (u128)y[(size_t)x * yo + (size_t)s * N + c] * tab.f[s][t];
-    out[(size_t)x * oo + (size_t)t * N + c] = reduce128(acc, M);
+    const int x = blockIdx.y;
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    ulonglong2 v[HY_MAX_DIGIT];
+#pragma unroll
+    for (int s = 0; s < HY_MAX_DIGIT; s++)
+        if (s < tab.ns) v[s] = *reinterpret_cast<const ulonglong2 *>(y + (size_t)x * yo + (size_t)s * N + c);
+    for (int t = 0; t < tab.nt; t++) {
+        if (t >= tab.skip_lo && t < tab.skip_hi) continue;
+        const ModC M = mod[dsel.mod[t]];
+        u128 ax = 0, ay = 0;
+#pragma unroll
+        for (int s = 0; s < HY_MAX_DIGIT; s++)
+            if (s < tab.ns) {
+                ax += (u128)v[s].x * tab.f[s][t];
+                ay += (u128)v[s].y * tab.f[s][t];
+            }
+        ulonglong2 r;
+        r.x = reduce128(ax, M);
+        r.y = reduce128(ay, M);
+        *reinterpret_cast<ulonglong2 *>(out + (size_t)x * oo + (size_t)t * N + c) = r;
+    }
 }
 // grid (N/512, nE, X); 2 coefficients per thread, both key polys
 __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ mod, int N, const u64 *__restrict__ dig,
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ 
 __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict__ mod, int logN,
                                                          const u64 *__restrict__ acc, int acc_limbs,
                                                          const u64 *__restrict__ conv, const u64 *__restrict__ addend,
-                                                         size_t axs, int add_polys, u64 *__restrict__ out, int nl,
+                                                         size_t axs, size_t aps, int add_polys, u64 *__restrict__ out, int nl,
                                                          ScaleSel pinv, const unsigned *__restrict__ galois,
                                                          int same_g) {
     const int N = 1 << logN;
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict_
     }
     u64 v = submod(acc[((size_t)xp * acc_limbs + j) * N + c], conv[((size_t)xp * nl + j) * N + c], q);
     v = mulmod_shoup(v, pinv.s[j], pinv.s_sh[j], q);
-    if (addend && p < add_polys) v = addmod(v, addend[(size_t)x * axs + ((size_t)p * nl + j) * N + c], q);
+    if (addend && p < add_polys) v = addmod(v, addend[(size_t)x * axs + (size_t)p * aps + (size_t)j * N + c], q);
     out[((size_t)xp * nl + j) * N + co] = v;
 }
 // grid (N/256, l, X)
@@ -251,59 +268,76 @@ __global__ __launch_bounds__(256) void k_rescale_spread(const ModC *__restrict__
 }
 __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict__ mod, int N, const u64 *__restrict__ in,
                                                          const u64 *__restrict__ tmp, u64 *__restrict__ out, int l,
-                                                         ScaleSel qlinv) {
+                                                         ScaleSel qlinv, int in_ls) {
     const int j = blockIdx.y, x = blockIdx.z;
     const u64 q = mod[j].q;
     const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const u64 v = submod(in[((size_t)x * (l + 1) + j) * N + c], tmp[((size_t)x * l + j) * N + c], q);
+    const u64 v = submod(in[((size_t)x * in_ls + j) * N + c], tmp[((size_t)x * l + j) * N + c], q);
     out[((size_t)x * l + j) * N + c] = mulmod_shoup(v, qlinv.s[j], qlinv.s_sh[j], q);
 }
 
 // ------------------------------------------------------------------------------------------------ loop B
 // acc[g][{d0,d1,d2}][j][c] = sum_{i<dim} rot[i] (x) db[g][i] with 128-bit lazy accumulation: one double-word
 // Barrett per output instead of 4*dim reductions.  45/46-bit limbs never overflow (dim * 2^93 < 2^128); the 60-bit
-// limb folds its accumulators every 64 diagonals.  grid (N/512, nl, G): 16 B per lane per operand.
+// limb folds its accumulators every 64 diagonals.  16 B per lane per operand (1 KiB per wave instruction).
+// Each thread serves BPP database blocks with ONE read of the rotated query, and the block-group index is the
+// FASTEST grid dimension, so the workgroups that stream the same rot tile run together and share it through L2 /
+// Infinity Cache: HBM sees rot once instead of once per block.  grid (tiles * G/BPP, nl).
+template <int BPP>
 __global__ __launch_bounds__(256) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
                                                       const u64 *__restrict__ db, u64 *__restrict__ acc, int dim,
-                                                      int nl) {
-    const int j = blockIdx.y, g = blockIdx.z;
+                                                      int nl, int Gp) {
+    const int j = blockIdx.y;
+    const int gp = blockIdx.x % Gp, tile = blockIdx.x / Gp;
     const ModC M = mod[j];
-    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t c = (size_t)(tile * 256 + threadIdx.x) * 2;
     const size_t ps = (size_t)nl * N, cs = 2 * ps;  // poly stride, ciphertext stride
     const u64 *ra = rot + (size_t)j * N + c;
-    const u64 *da = db + (size_t)g * dim * cs + (size_t)j * N + c;
+    const u64 *da = db + (size_t)gp * BPP * dim * cs + (size_t)j * N + c;
+    const size_t bs = (size_t)dim * cs;  // block stride
     const int kbits = M.ks + 2;
     const int chunk = (126 - 2 * kbits >= 30) ? dim : (1 << (126 - 2 * kbits));
-    u128 d0x = 0, d0y = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
+    u128 d0x[BPP], d0y[BPP], d1x[BPP], d1y[BPP], d2x[BPP], d2y[BPP];
+#pragma unroll
+    for (int u = 0; u < BPP; u++) d0x[u] = d0y[u] = d1x[u] = d1y[u] = d2x[u] = d2y[u] = 0;
     for (int i0 = 0; i0 < dim; i0 += chunk) {
         const int i1 = i0 + chunk < dim ? i0 + chunk : dim;
-#pragma unroll 4
+#pragma unroll 2
         for (int i = i0; i < i1; i++) {
             const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
             const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs + ps);
-            const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(da + (size_t)i * cs);
-            const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(da + (size_t)i * cs + ps);
-            d0x += (u128)a0.x * b0.x;
-            d0y += (u128)a0.y * b0.y;
-            d1x += (u128)a0.x * b1.x + (u128)a1.x * b0.x;
-            d1y += (u128)a0.y * b1.y + (u128)a1.y * b0.y;
-            d2x += (u128)a1.x * b1.x;
-            d2y += (u128)a1.y * b1.y;
+#pragma unroll
+            for (int u = 0; u < BPP; u++) {
+                const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(da + u * bs + (size_t)i * cs);
+                const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(da + u * bs + (size_t)i * cs + ps);
+                d0x[u] += (u128)a0.x * b0.x;
+                d0y[u] += (u128)a0.y * b0.y;
+                d1x[u] += (u128)a0.x * b1.x + (u128)a1.x * b0.x;
+                d1y[u] += (u128)a0.y * b1.y + (u128)a1.y * b0.y;
+                d2x[u] += (u128)a1.x * b1.x;
+                d2y[u] += (u128)a1.y * b1.y;
+            }
         }
         if (i1 < dim) {
-            d0x = reduce128(d0x, M); d0y = reduce128(d0y, M);
-            d1x = reduce128(d1x, M); d1y = reduce128(d1y, M);
-            d2x = reduce128(d2x, M); d2y = reduce128(d2y, M);
+#pragma unroll
+            for (int u = 0; u < BPP; u++) {
+                d0x[u] = reduce128(d0x[u], M); d0y[u] = reduce128(d0y[u], M);
+                d1x[u] = reduce128(d1x[u], M); d1y[u] = reduce128(d1y[u], M);
+                d2x[u] = reduce128(d2x[u], M); d2y[u] = reduce128(d2y[u], M);
+            }
         }
     }
-    ulonglong2 r0, r1, r2;
-    r0.x = reduce128(d0x, M); r0.y = reduce128(d0y, M);
-    r1.x = reduce128(d1x, M); r1.y = reduce128(d1y, M);
-    r2.x = reduce128(d2x, M); r2.y = reduce128(d2y, M);
-    u64 *o = acc + ((size_t)g * 3 * nl + j) * N + c;
-    *reinterpret_cast<ulonglong2 *>(o) = r0;
-    *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
-    *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
+#pragma unroll
+    for (int u = 0; u < BPP; u++) {
+        ulonglong2 r0, r1, r2;
+        r0.x = reduce128(d0x[u], M); r0.y = reduce128(d0y[u], M);
+        r1.x = reduce128(d1x[u], M); r1.y = reduce128(d1y[u], M);
+        r2.x = reduce128(d2x[u], M); r2.y = reduce128(d2y[u], M);
+        u64 *o = acc + ((size_t)(gp * BPP + u) * 3 * nl + j) * N + c;
+        *reinterpret_cast<ulonglong2 *>(o) = r0;
+        *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
+        *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill_uniform_hash(const ModC *__restrict__ mod, int N, u64 *__restrict__ dst,
@@ -323,8 +357,13 @@ __global__ __launch_bounds__(256) void k_fill_uniform_hash(const ModC *__restric
 // ================================================================================================ launchers
 namespace hk {
 
+static bool use_generic_ntt() {
+    static const bool g = getenv("HYDIA_NTT_GENERIC") != nullptr;
+    return g;
+}
 void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                  const LimbSel &sel) {
+    if (logN == 15 && !use_generic_ntt()) return ntt15_forward(st, T, src, dst, so, dso, X, sel);
     const int N = 1 << logN, R = N >> 8;
     ScaleSel dummy = {};
     hipLaunchKernelGGL(k_ntt_strided<false>, dim3(8, X * sel.n), dim3(256), (size_t)R * 32 * 8, st, T, logN, src, dst, so,
@@ -333,20 +372,23 @@ void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u
 }
 void ntt_inverse(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                  const LimbSel &sel, const ScaleSel &scale) {
+    if (logN == 15 && !use_generic_ntt()) return ntt15_inverse(st, T, src, dst, so, dso, X, sel, scale);
     const int N = 1 << logN, R = N >> 8;
     hipLaunchKernelGGL(k_ntt_contig<true>, dim3(N / 2048, X * sel.n), dim3(256), 0, st, T, logN, src, dst, so, dso, sel);
     hipLaunchKernelGGL(k_ntt_strided<true>, dim3(8, X * sel.n), dim3(256), (size_t)R * 32 * 8, st, T, logN, dst, dst, dso,
                        dso, sel, scale);
 }
-void add(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, const LimbSel &sel) {
-    hipLaunchKernelGGL(k_addsub<0>, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel);
+void add(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
+         int b_ls, int o_ls) {
+    hipLaunchKernelGGL(k_addsub<0>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
 }
-void sub(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, const LimbSel &sel) {
-    hipLaunchKernelGGL(k_addsub<1>, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel);
+void sub(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
+         int b_ls, int o_ls) {
+    hipLaunchKernelGGL(k_addsub<1>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
 }
-void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, int X, const LimbSel &sel,
-                const ScaleSel &c) {
-    hipLaunchKernelGGL(k_mul_scalar, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, o, sel, c);
+void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, int XP, const LimbSel &sel,
+                const ScaleSel &c, int a_ls, int o_ls) {
+    hipLaunchKernelGGL(k_mul_scalar, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, o, sel, c, a_ls, o_ls);
 }
 void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,
                 const ScaleSel &c) {
@@ -355,12 +397,12 @@ void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, in
 void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t so, size_t dso, int X, int nlimbs) {
     hipLaunchKernelGGL(k_copy_limbs, dim3(N / 512, X * nlimbs), dim3(256), 0, st, N, src, dst, so, dso, nlimbs);
 }
-void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl) {
-    hipLaunchKernelGGL(k_tensor, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl);
+void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls) {
+    hipLaunchKernelGGL(k_tensor, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl, a_ls, b_ls);
 }
 void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, u64 *out, size_t oo, int X,
                   const ConvTab &tab, const LimbSel &dsel) {
-    hipLaunchKernelGGL(k_base_convert, dim3(N / 256, tab.nt, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
+    hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
                    int same_key, int nT, u64 *acc, int X, const LimbSel &esel) {
@@ -368,21 +410,27 @@ void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_
                        nT, acc, esel);
 }
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
-                     const u64 *addend, size_t axs, int add_polys, u64 *out, int X, int nl, const ScaleSel &pinv,
-                     const unsigned *galois, int same_g) {
+                     const u64 *addend, size_t axs, size_t aps, int add_polys, u64 *out, int X, int nl,
+                     const ScaleSel &pinv, const unsigned *galois, int same_g) {
     hipLaunchKernelGGL(k_moddown_combine, dim3((1 << logN) / 256, nl, X * 2), dim3(256), 0, st, mod, logN, acc, acc_limbs,
-                       conv, addend, axs, add_polys, out, nl, pinv, galois, same_g);
+                       conv, addend, axs, aps, add_polys, out, nl, pinv, galois, same_g);
 }
 void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l) {
     hipLaunchKernelGGL(k_rescale_spread, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, t, tmp, l);
 }
 void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, const u64 *tmp, u64 *out, int X, int l,
-                     const ScaleSel &qlinv) {
-    hipLaunchKernelGGL(k_rescale_combine, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, in, tmp, out, l, qlinv);
+                     const ScaleSel &qlinv, int in_ls) {
+    hipLaunchKernelGGL(k_rescale_combine, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, in, tmp, out, l, qlinv, in_ls);
 }
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
-                             int dim, int nl) {
-    hipLaunchKernelGGL(k_hydia_tensor, dim3(N / 512, nl, G), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl);
+                             int dim, int nl, int bpp) {
+    const int tiles = N / 512;
+    if (bpp >= 4 && G % 4 == 0)
+        hipLaunchKernelGGL(k_hydia_tensor<4>, dim3(tiles * (G / 4), nl), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl, G / 4);
+    else if (bpp >= 2 && G % 2 == 0)
+        hipLaunchKernelGGL(k_hydia_tensor<2>, dim3(tiles * (G / 2), nl), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl, G / 2);
+    else
+        hipLaunchKernelGGL(k_hydia_tensor<1>, dim3(tiles * G, nl), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl, G);
 }
 const char *hydia_tensor_kernel_name() { return "k_hydia_tensor"; }
 void fill_uniform_hash(hipStream_t st, const ModC *mod, int N, u64 *dst, size_t n_limbpolys, int nl,

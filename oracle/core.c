@@ -8,6 +8,7 @@
  * this build's own deterministic rule (OpenFHE's is not recoverable offline); they change no decrypted
  * result.
  */
+#define _GNU_SOURCE /* sincos */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -174,9 +175,12 @@ hy_params *hyo_params_create(int logN, int mult_depth, int scale_bits, int first
     p->ksi_re = (double *)malloc(sizeof(double) * (M + 1));
     p->ksi_im = (double *)malloc(sizeof(double) * (M + 1));
     for (u64 k = 0; k <= M; k++) {
-        double ang = 2.0 * M_PI * (double)k / (double)M;
-        p->ksi_re[k] = cos(ang);
-        p->ksi_im[k] = sin(ang);
+        /* glibc sincos() on both sides of the parity tests: a compiler may or may not fuse separate sin()/cos()
+         * calls into sincos(), and the two entry points are not guaranteed to round identically */
+        double ang = 2.0 * M_PI * (double)k / (double)M, sn, cs;
+        sincos(ang, &sn, &cs);
+        p->ksi_re[k] = cs;
+        p->ksi_im[k] = sn;
     }
     return p;
 }

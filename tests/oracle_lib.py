@@ -25,6 +25,8 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # GPU boxes expose every hardware thread but grant a 16-core share: unbounded OpenMP teams oversubscribe badly
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     path = os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path):
         build()
