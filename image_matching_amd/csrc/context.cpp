@@ -286,11 +286,30 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
         HIP_CHECK(hipMalloc((void **)&d_itwp, 2 * tb));
         HIP_CHECK(hipMemcpy(d_twp, pr.data(), 2 * tb, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_itwp, ipr.data(), 2 * tb, hipMemcpyHostToDevice));
+        // FP64 path: (w, w/q) as doubles (exact for the <= 47-bit primes; never read for the 60-bit ones)
+        std::vector<double> fr(2 * (size_t)nT * N), ifr(2 * (size_t)nT * N);
+        for (int m = 0; m < nT; m++)
+            for (int k = 0; k < N; k++) {
+                const size_t i = (size_t)m * N + k;
+                const double qd = (double)q[m];
+                fr[2 * i] = (double)tw[i];
+                fr[2 * i + 1] = (double)tw[i] / qd;
+                ifr[2 * i] = (double)itw[i];
+                ifr[2 * i + 1] = (double)itw[i] / qd;
+            }
+        HIP_CHECK(hipMalloc((void **)&d_twf, 2 * tb));
+        HIP_CHECK(hipMalloc((void **)&d_itwf, 2 * tb));
+        HIP_CHECK(hipMemcpy(d_twf, fr.data(), 2 * tb, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_itwf, ifr.data(), 2 * tb, hipMemcpyHostToDevice));
     }
-    tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod, (const ulonglong2 *)d_twp, (const ulonglong2 *)d_itwp};
+    tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod, (const ulonglong2 *)d_twp, (const ulonglong2 *)d_itwp,
+                     (const ulonglong2 *)d_twf, (const ulonglong2 *)d_itwf};
+    if (getenv("HYDIA_NTT_INT")) tabs.twf = tabs.itwf = nullptr;  // A/B switch: integer butterflies for every limb
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
+    if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
     HIP_CHECK(hipMalloc((void **)&d_rotptrs, sizeof(u64 *) * (size_t)p.dim));
     HIP_CHECK(hipMalloc((void **)&d_rotgalois, sizeof(unsigned) * (size_t)p.dim));
+    HIP_CHECK(hipMalloc((void **)&d_rotginv, sizeof(unsigned) * (size_t)p.dim));
 
 }
 
@@ -307,9 +326,9 @@ Context::~Context() {
     for (auto &kv : rot_keys)
         for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
             if (p) (void)hipFree(p);
-    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp,
+    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp, (void *)d_twf, (void *)d_itwf,
                     (void *)d_rotptrs,
-                    (void *)d_rotgalois, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
+                    (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -361,11 +380,17 @@ u64 *Context::eval_key_storage(int rot) {
         const size_t bytes = (size_t)prm.dnum * 2 * nT * N * sizeof(u64);
         HIP_CHECK(hipMalloc((void **)&k.d, bytes));
         HIP_CHECK(hipMalloc((void **)&k.d_cell, sizeof(u64 *)));
-        HIP_CHECK(hipMalloc((void **)&k.d_gal, sizeof(unsigned)));
+        HIP_CHECK(hipMalloc((void **)&k.d_gal, 2 * sizeof(unsigned)));
         const u64 *self = k.d;
-        unsigned g = rot == 0 ? 1u : (unsigned)galois_elt(rot);
+        unsigned g[2] = {1u, 1u};
+        if (rot != 0) {
+            g[0] = (unsigned)galois_elt(rot);
+            u64 x = 1;  // inverse of an odd number modulo the power of two 2N (Newton)
+            for (int i = 0; i < 6; i++) x = x * (2 - (u64)g[0] * x);
+            g[1] = (unsigned)(x & (2ull * N - 1));
+        }
         HIP_CHECK(hipMemcpy((void *)k.d_cell, &self, sizeof(u64 *), hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(k.d_gal, &g, sizeof(unsigned), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(k.d_gal, g, 2 * sizeof(unsigned), hipMemcpyHostToDevice));
         rotptrs_valid = false;
     }
     return k.d;

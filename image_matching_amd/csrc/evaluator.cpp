@@ -59,12 +59,30 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
         }
         ntt_inv(c + (size_t)lo * N, y, c_outer, (size_t)sz * N, X, dsel, scale_of(dsel, inv, true));
         u64 *out = dig + (size_t)d * nE * N;
-        hk::base_convert(stream, d_mod, N, y, (size_t)sz * N, out, dig_x, X, tab, esel);
-        if (lo > 0) ntt_fwd(out, dig_x, X, sel_range(0, lo));
         LimbSel rest{};
         rest.n = nE - hi;
         for (int t = hi; t < nE; t++) rest.mod[t - hi] = esel.mod[t];
-        ntt_fwd(out + (size_t)hi * N, dig_x, X, rest);
+        if (prm.logN == 15) {
+            // base conversion fused into the forward NTT's first pass: the converted residues never touch HBM
+            NttLoad ld{};
+            ld.mode = 1;
+            ld.y = y;
+            ld.y_outer = (size_t)sz * N;
+            ld.tab = tab;
+            NttStore stp{};
+            if (lo > 0) {
+                ld.t0 = 0;
+                hk::ntt15_forward_fused(stream, tabs, nullptr, out, 0, dig_x, X, sel_range(0, lo), ld, stp);
+            }
+            if (rest.n > 0) {
+                ld.t0 = hi;
+                hk::ntt15_forward_fused(stream, tabs, nullptr, out + (size_t)hi * N, 0, dig_x, X, rest, ld, stp);
+            }
+        } else {
+            hk::base_convert(stream, d_mod, N, y, (size_t)sz * N, out, dig_x, X, tab, esel);
+            if (lo > 0) ntt_fwd(out, dig_x, X, sel_range(0, lo));
+            ntt_fwd(out + (size_t)hi * N, dig_x, X, rest);
+        }
         hk::copy_limbs(stream, N, c + (size_t)lo * N, out + (size_t)lo * N, c_outer, dig_x, X, sz);
     }
     pool.put(y);
@@ -74,7 +92,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
 // automorphism (EvalFastRotation's tail).  out: [X][2][nl][N].
 void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
                        const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys,
-                       const unsigned *d_galois, int same_galois, u64 *out) {
+                       const unsigned *d_galois, const unsigned *d_ginv, int same_galois, bool dbl, u64 *out) {
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
@@ -93,11 +111,38 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
         for (int j = 0; j < nl; j++) tab.f[k][j] = Phat_mod_q[k][j];
     u64 *conv = pool.get((size_t)X * 2 * nl * N * sizeof(u64));
     const LimbSel qsel = sel_q(nl);
-    hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
-    ntt_fwd(conv, (size_t)nl * N, X * 2, qsel);
     std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
-    hk::moddown_combine(stream, d_mod, prm.logN, acc, nE, conv, addend, add_x_stride, add_poly_stride, add_polys, out, X, nl,
-                        scale_of(qsel, pinv, false), d_galois, same_galois);
+    if (prm.logN == 15) {
+        // P -> Q base conversion fused into the NTT's first pass, ModDown combine (+ addend, doubling, automorphism
+        // scatter) fused into its second pass: `conv` is only the inter-pass scratch
+        NttLoad ld{};
+        ld.mode = 1;
+        ld.y = y;
+        ld.y_outer = (size_t)nP * N;
+        ld.tab = tab;
+        ld.t0 = 0;
+        NttStore stp{};
+        stp.mode = 1;
+        stp.out = out;
+        stp.nl = nl;
+        stp.in = acc;
+        stp.in_ls = nE;
+        stp.mul = scale_of(qsel, pinv, false);
+        stp.addend = addend;
+        stp.add_x = add_x_stride;
+        stp.add_p = add_poly_stride;
+        stp.add_polys = add_polys;
+        stp.dbl = dbl ? 1 : 0;
+        stp.ginv = d_ginv;
+        stp.same_g = same_galois;
+        hk::ntt15_forward_fused(stream, tabs, nullptr, conv, 0, (size_t)nl * N, X * 2, qsel, ld, stp);
+    } else {
+        hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
+        ntt_fwd(conv, (size_t)nl * N, X * 2, qsel);
+        hk::moddown_combine(stream, d_mod, prm.logN, acc, nE, conv, addend, add_x_stride, add_poly_stride, add_polys, out, X, nl,
+                            scale_of(qsel, pinv, false), d_galois, same_galois);
+        if (dbl) hk::add(stream, d_mod, N, out, out, out, X * 2, qsel, nl, nl, nl);
+    }
     pool.put(conv);
     pool.put(y);
     pool.put(acc);
@@ -106,44 +151,78 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
 void Context::build_rotptrs() {
     if (rotptrs_valid) return;
     std::vector<const u64 *> ptrs(prm.dim, nullptr);
-    std::vector<unsigned> gal(prm.dim, 1u);
+    std::vector<unsigned> gal(prm.dim, 1u), ginv(prm.dim, 1u);
     for (int i = 1; i < prm.dim; i++) {
         auto it = rot_keys.find(i);
         if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(i) + " not loaded");
         ptrs[i] = it->second.d;
         gal[i] = (unsigned)galois_elt(i);
+        u64 x = 1;
+        for (int it = 0; it < 6; it++) x = x * (2 - (u64)gal[i] * x);
+        ginv[i] = (unsigned)(x & (2ull * N - 1));
     }
+    HIP_CHECK(hipMemcpy(d_rotginv, ginv.data(), sizeof(unsigned) * prm.dim, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy((void *)d_rotptrs, ptrs.data(), sizeof(u64 *) * prm.dim, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_rotgalois, gal.data(), sizeof(unsigned) * prm.dim, hipMemcpyHostToDevice));
     rotptrs_valid = true;
 }
 
 // RelinearizeInPlace (sender_diag.cpp:79)
-void Context::relinearize(Ct &c) {
+void Context::relinearize(Ct &c, bool dbl) {
     if (c.npoly != 3) return;
     if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
     const int nl = c.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, c.scale);
-    ks_apply(dig, (size_t)nd * nE * N, X, nl, relin_key.d_cell, 1, c.d, c.ct_elems(), c.poly_elems(), 2, nullptr, 0, out.d);
+    ks_apply(dig, (size_t)nd * nE * N, X, nl, relin_key.d_cell, 1, c.d, c.ct_elems(), c.poly_elems(), 2, nullptr, nullptr, 0, dbl,
+             out.d);
     pool.put(dig);
     c = std::move(out);
 }
 // RescaleInPlace (sender_diag.cpp:80): divide by the last prime with rounding to nearest
-void Context::rescale(Ct &c) {
+void Context::rescale(Ct &c, const Ct *sub, const double *addc) {
     const int nl = c.nl, l = nl - 1, XP = c.X * c.npoly;
     if (nl < 2) throw std::runtime_error("hydia: rescale with one limb left");
+    if (sub && (sub->X != c.X || sub->npoly != c.npoly || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
     u64 *t = pool.get((size_t)XP * N * sizeof(u64));
     const LimbSel last = sel_range(l, l + 1);
     ntt_inv(c.d + (size_t)l * N, t, c.poly_elems(), (size_t)N, XP, last, scale_ninv(last));
     u64 *tmp = pool.get((size_t)XP * l * N * sizeof(u64));
-    hk::rescale_spread(stream, d_mod, N, t, tmp, XP, l);
     const LimbSel qsel = sel_q(l);
-    ntt_fwd(tmp, (size_t)l * N, XP, qsel);
     Ct out(this, c.X, c.npoly, l, c.scale / (double)q[l]);
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
-    hk::rescale_combine(stream, d_mod, N, c.d, tmp, out.d, XP, l, scale_of(qsel, qi, false), c.lstride);
+    if (prm.logN == 15 && l <= HY_LC_LIMBS) {
+        // spread fused into the NTT's first pass, combine (+ the caller's subtraction / constant) into its second
+        NttLoad ld{};
+        ld.mode = 2;
+        ld.y = t;
+        ld.y_outer = (size_t)N;
+        ld.l = l;
+        NttStore stp{};
+        stp.mode = 2;
+        stp.out = out.d;
+        stp.nl = l;
+        stp.in = c.d;
+        stp.in_ls = c.lstride;
+        stp.mul = scale_of(qsel, qi, false);
+        stp.sub = sub ? sub->d : nullptr;
+        stp.sub_ls = sub ? sub->lstride : 0;
+        stp.has_addc = addc ? 1 : 0;
+        stp.npoly = c.npoly;
+        if (addc)
+            for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out.scale, q[j]);
+        hk::ntt15_forward_fused(stream, tabs, nullptr, tmp, 0, (size_t)l * N, XP, qsel, ld, stp);
+    } else {
+        hk::rescale_spread(stream, d_mod, N, t, tmp, XP, l);
+        ntt_fwd(tmp, (size_t)l * N, XP, qsel);
+        hk::rescale_combine(stream, d_mod, N, c.d, tmp, out.d, XP, l, scale_of(qsel, qi, false), c.lstride);
+        if (sub) {
+            Ct sv = sub->alias(l);
+            sub_inplace(out, sv);
+        }
+        if (addc) add_const(out, *addc);
+    }
     pool.put(tmp);
     pool.put(t);
     c = std::move(out);
@@ -186,6 +265,27 @@ Ct Context::mul_const(const Ct &a, double c, double const_scale) {
     hk::mul_scalar(stream, d_mod, N, a.d, o.d, a.X * a.npoly, s, sc, a.lstride, o.lstride);
     return o;
 }
+Ct Context::lincomb(const std::vector<const Ct *> &terms, const std::vector<double> &coef, double c0, double S) {
+    if (terms.empty() || terms.size() > HY_LC_TERMS || terms.size() != coef.size()) throw std::runtime_error("hydia: bad lincomb");
+    const Ct &f = *terms[0];
+    if (f.nl > HY_LC_LIMBS) throw std::runtime_error("hydia: lincomb limb count");
+    LinComb lc{};
+    lc.nterms = (int)terms.size();
+    for (int t = 0; t < lc.nterms; t++) {
+        const Ct &a = *terms[t];
+        if (a.X != f.X || a.npoly != f.npoly || a.nl != f.nl) throw std::runtime_error("hydia: lincomb shape mismatch");
+        lc.src[t] = a.d;
+        lc.ls[t] = a.lstride;
+        for (int j = 0; j < f.nl; j++) {
+            lc.c[t][j] = double_to_mod(coef[t] * (S / a.scale), q[j]);
+            lc.cs[t][j] = shoup_h(lc.c[t][j], q[j]);
+        }
+    }
+    for (int j = 0; j < f.nl; j++) lc.c0[j] = double_to_mod(c0 * S, q[j]);
+    Ct o(this, f.X, f.npoly, f.nl, S);
+    hk::lincomb(stream, d_mod, N, lc, o.d, f.X, f.npoly, f.nl);
+    return o;
+}
 // EvalMultNoRelin (sender_diag.cpp:93)
 Ct Context::mult_norelin(const Ct &a, const Ct &b) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
@@ -209,8 +309,8 @@ Ct Context::rotate(const Ct &a, int rot) {
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(a.d + a.poly_elems(), a.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, a.scale);
-    ks_apply(dig, (size_t)nd * nE * N, X, nl, it->second.d_cell, 1, a.d, a.ct_elems(), a.poly_elems(), 1, it->second.d_gal, 1,
-             out.d);
+    ks_apply(dig, (size_t)nd * nE * N, X, nl, it->second.d_cell, 1, a.d, a.ct_elems(), a.poly_elems(), 1, it->second.d_gal,
+             it->second.d_gal + 1, 1, false, out.d);
     pool.put(dig);
     return out;
 }
@@ -227,7 +327,8 @@ Ct Context::rotate_query(const Ct &qc) {
     Ct rot(this, dim, 2, nl, qc.scale);
     HIP_CHECK(hipMemcpyAsync(rot.d, qc.d, qc.bytes(), hipMemcpyDeviceToDevice, stream));
     if (dim > 1)
-        ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + 1, 0, rot.d + rot.ct_elems());
+        ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + 1, d_rotginv + 1, 0, false,
+                 rot.d + rot.ct_elems());
     pool.put(dig);
     return rot;
 }
@@ -240,7 +341,7 @@ Ct Context::similarity(const Ct &qc) {
     Ct rot = rotate_query(qc);
     Ct acc(this, G, 3, nQ, qc.scale * delta);
     timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp);
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw);
     timer_end("hydia_tensor");
     relinearize(acc);
     rescale(acc);
@@ -254,20 +355,16 @@ struct Cheb {
     std::vector<Ct> T;  // T[1..8]
     std::vector<Ct> G;  // G[i] = T_{8*2^i}; G[0] is a view of T[8]
 };
-// 2ab - c (c == nullptr: the constant 1)
+// 2ab - c (c == nullptr: the constant 1): tensor, relinearise (doubling fused into its last pass), rescale (the
+// subtraction fused into its last pass) — same operation order as the oracle: relin, x2, rescale, -c
 Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
     Ct o = cx->mult_norelin(x, y);
-    cx->relinearize(o);
-    cx->add_inplace(o, o);
-    cx->rescale(o);
-    if (c) {
-        Ct cc = c->alias(o.nl);
-        cx->sub_inplace(o, cc);
-    } else {
-        cx->add_const(o, -1.0);
-    }
+    cx->relinearize(o, true);
+    const double minus_one = -1.0;
+    if (c) cx->rescale(o, c, nullptr);
+    else cx->rescale(o, nullptr, &minus_one);
     return o;
 }
 Ct cheb_leaf(Cheb &ch, const double *c, int deg) {
@@ -280,18 +377,19 @@ Ct cheb_leaf(Cheb &ch, const double *c, int deg) {
             nl = std::min(nl, ch.T[j].nl);
         }
     const double S = cx->delta * (double)cx->q[nl - 1];
-    Ct acc;
+    // one fused pass: sum_j c_j T_j + c_0 with every constant encoded at S / scale(T_j) (a pure constant is 0*T_1 + c_0)
+    std::vector<Ct> views;
+    std::vector<double> coef;
     const int last = any ? deg : 1;
     for (int j = 1; j <= last; j++) {
         const double cj = any ? c[j] : 0.0;
         if (cj == 0.0 && any) continue;
-        Ct t = ch.T[j].alias(nl);
-        Ct m = cx->mul_const(t, cj, S / t.scale);
-        m.scale = S;
-        if (!acc.d) acc = std::move(m);
-        else cx->add_inplace(acc, m);
+        views.push_back(ch.T[j].alias(nl));
+        coef.push_back(cj);
     }
-    cx->add_const(acc, c[0]);
+    std::vector<const Ct *> terms;
+    for (auto &v : views) terms.push_back(&v);
+    Ct acc = cx->lincomb(terms, coef, c[0], S);
     cx->rescale(acc);
     return acc;
 }
@@ -372,18 +470,12 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     const int nl = y3.nl;
     const double S = delta * (double)q[nl - 1];
     Ct yd = y.alias(nl);
-    Ct u = mul_const(yd, F4[1], S / yd.scale), t = mul_const(y3, F4[3], S / y3.scale);
-    u.scale = t.scale = S;
-    add_inplace(u, t);
+    Ct u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, S);
     rescale(u);
-    Ct v = mul_const(yd, F4[5], S / yd.scale);
-    t = mul_const(y3, F4[7], S / y3.scale);
-    v.scale = t.scale = S;
-    add_inplace(v, t);
+    Ct v = lincomb({&yd, &y3}, {F4[5], F4[7]}, 0.0, S);
     rescale(v);
     const double S0 = delta * (double)q[y.nl - 1];
-    Ct w = mul_const(y, F4[9], S0 / y.scale);
-    w.scale = S0;
+    Ct w = lincomb({&y}, {F4[9]}, 0.0, S0);
     rescale(w);
     Ct a = mult(v, y4), b = mult(w, y8);
     const int fl = std::min(std::min(a.nl, b.nl), u.nl);

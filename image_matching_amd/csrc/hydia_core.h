@@ -92,7 +92,7 @@ struct Context : HostParams {
 
     // device tables
     ModC *d_mod = nullptr;
-    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr, *d_twp = nullptr, *d_itwp = nullptr;
+    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr, *d_twp = nullptr, *d_itwp = nullptr, *d_twf = nullptr, *d_itwf = nullptr;
     NttTables tabs{};
 
     // evaluation keys resident in HBM: [dnum][2][nT][N]; each carries a one-element device cell holding its own
@@ -100,12 +100,13 @@ struct Context : HostParams {
     struct EvalKey {
         u64 *d = nullptr;
         const u64 **d_cell = nullptr;
-        unsigned *d_gal = nullptr;
+        unsigned *d_gal = nullptr;   // [0] = Galois element g, [1] = g^{-1} mod 2N
     };
     EvalKey relin_key;
     std::map<int, EvalKey> rot_keys;
     const u64 **d_rotptrs = nullptr;   // device array: key pointers of rotations 1..dim-1 (hoisted loop A)
     unsigned *d_rotgalois = nullptr;   // device array: their Galois elements
+    unsigned *d_rotginv = nullptr;     // device array: inverse Galois elements (scatter form of the automorphism)
     bool rotptrs_valid = false;
     void load_eval_key(int rot /* 0 = relinearisation */, const u64 *host);
     u64 *eval_key_storage(int rot);    // allocates (or returns) the HBM buffer of key `rot`
@@ -141,17 +142,21 @@ struct Context : HostParams {
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
     void ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
                   const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys, const unsigned *d_galois,
-                  int same_galois, u64 *out);
+                  const unsigned *d_ginv, int same_galois, bool dbl, u64 *out);
     void build_rotptrs();
-    void relinearize(Ct &c);  // [X][3][nl] -> [X][2][nl]
-    void rescale(Ct &c);      // drop the last limb
+    void relinearize(Ct &c, bool dbl = false);  // [X][3][nl] -> [X][2][nl]; dbl: result doubled (2ab of a Chebyshev step)
+    // drop the last limb; optionally fused: result -= sub (a view at the new level), result += addc (constant, poly 0)
+    void rescale(Ct &c, const Ct *sub = nullptr, const double *addc = nullptr);
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
-    int tensor_bpp = 4;             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
+    int tensor_bpp = 4;             // DB blocks per wave in loop B (HYDIA_TENSOR_BPP)
+    int tensor_nw = 0;              // waves per workgroup in loop B, 0 = as many as divide (HYDIA_TENSOR_NW)             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
     void add_inplace(Ct &a, const Ct &b);
     void sub_inplace(Ct &a, const Ct &b);
     void add_const(Ct &a, double c);
     Ct mul_const(const Ct &a, double c, double const_scale);
+    // sum_t coef[t] * terms[t] + c0 at common scale S (each constant encoded at S / scale(term)); all terms same X, npoly, nl
+    Ct lincomb(const std::vector<const Ct *> &terms, const std::vector<double> &coef, double c0, double S);
     Ct mult_norelin(const Ct &a, const Ct &b);
     Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale
     Ct rotate(const Ct &a, int rot);    // X = any; full key switch

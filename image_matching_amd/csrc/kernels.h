@@ -18,6 +18,7 @@ struct NttTables {
     const u64 *itw, *itw_sh;  // [nT][N] psi^{-bitrev(k)}
     const ModC *mod;          // [nT]
     const ulonglong2 *twp, *itwp;  // the same tables interleaved as (w, w_shoup) pairs: one 16-byte load per twiddle
+    const ulonglong2 *twf, *itwf;  // bit patterns of double pairs (w, w / q) for the FP64 path of the <= 47-bit primes
 };
 
 // base conversion table: out[t] = sum_s y[s] * f[s][t] mod q_{dst t}
@@ -30,6 +31,49 @@ struct ConvTab {
 struct ScaleSel {  // per-limb multiplier applied by the inverse NTT's last pass (N^{-1} * extra)
     u64 s[HY_MAX_MODS], s_sh[HY_MAX_MODS];
 };
+
+#define HY_LC_TERMS 8
+#define HY_LC_LIMBS 16
+// linear combination of up to 8 ciphertext batches with per-limb constants (Chebyshev / f4 leaves)
+struct LinComb {
+    int nterms;
+    const u64 *src[HY_LC_TERMS];
+    int ls[HY_LC_TERMS];                   // limb stride of each source
+    u64 c[HY_LC_TERMS][HY_LC_LIMBS];       // constant residues per (term, limb)
+    u64 cs[HY_LC_TERMS][HY_LC_LIMBS];      // Shoup companions
+    u64 c0[HY_LC_LIMBS];                   // constant added to polynomial 0
+};
+
+// Fused prologue of the N = 2^15 forward NTT's first pass: where the coefficient-form input comes from
+struct NttLoad {
+    int mode;             // 0 plain (src), 1 fast base conversion from `y`, 2 rescale spread from `y`
+    const u64 *y;         // mode 1: [x][ns][N] source residues (coefficient form); mode 2: [x][N] last limb, coefficient form
+    size_t y_outer;       // elements between consecutive x
+    int l;                // mode 2: index of the dropped modulus q_l
+    ConvTab tab;          // mode 1: f[s][t] for target slot t (skip range ignored: launch only the wanted slots)
+    int t0;               // mode 1: target slot of sel slot 0 (tab column = t0 + slot)
+};
+// Fused epilogue of its second pass: what is done with the evaluation-form value v of limb j
+struct NttStore {
+    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine
+    u64 *out;             // modes 1,2: destination, compact [xp][nl][N]
+    int nl;               // limbs of `out`
+    const u64 *in;        // mode 1: acc [xp][in_ls][N] (Q limbs first); mode 2: ciphertext being rescaled [xp][in_ls][N]
+    int in_ls;
+    ScaleSel mul;         // mode 1: P^{-1} mod q_j; mode 2: q_l^{-1} mod q_j   -> out = (in - v) * mul
+    const u64 *addend;    // mode 1: + addend[x*add_x + p*add_p + j*N + c] for p < add_polys (xp = 2x + p)
+    size_t add_x, add_p;
+    int add_polys;
+    int dbl;              // mode 1: result doubled (Chebyshev recurrences 2ab - c)
+    const unsigned *ginv; // mode 1: scatter through the automorphism: out index = perm_{ginv[x]}(c); null = identity
+    int same_g;
+    const u64 *sub;       // mode 2: - sub[xp*sub_ls*N + j*N + c]
+    int sub_ls;
+    int has_addc;         // mode 2: + addc[j] on polynomials with xp % npoly == 0
+    int npoly;
+    u64 addc[HY_LC_LIMBS];
+};
+
 
 namespace hk {
 
@@ -44,6 +88,9 @@ void ntt15_forward(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
                    const LimbSel &sel);
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X,
                    const LimbSel &sel, const ScaleSel &scale);
+// forward transform with fused prologue / epilogue; dst is the [X][sel.n][N] scratch between the passes
+void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer,
+                         int X, const LimbSel &sel, const NttLoad &ld, const NttStore &stp);
 
 // ---- element-wise over [X][sel.n][N]
 // XP polynomials; operand t's polynomial xp starts at xp * t_ls * N (limb-strided views of dropped ciphertexts)
@@ -57,6 +104,8 @@ void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, in
                 const ScaleSel &c);  // a[x][slot] += c[slot]  (first sel.n slots of each outer block)
 void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X,
                 int nlimbs);
+// o[x][p][j] = sum_t src_t[x][p][j] * c[t][j] (+ c0[j] on p = 0): X cts of npoly polys, nl limbs, compact output
+void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl);
 // (a0 b0, a0 b1 + a1 b0, a1 b1) for X ciphertext pairs at nl limbs; o: [X][3][nl][N]
 void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls);
 
@@ -82,7 +131,7 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
 
 // ---- loop B of the HyDia sender: acc[g][3][nl][N] = sum_i rot[i] (x) db[g][i], fully reduced
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
-                             int dim, int nl, int bpp);
+                             int dim, int nl, int bpp, int nw);
 const char *hydia_tensor_kernel_name();
 
 // ---- misc

@@ -139,6 +139,29 @@ __global__ __launch_bounds__(256) void k_mul_scalar(const ModC *__restrict__ mod
     r.y = mulmod_shoup(va.y, c.s[slot], c.s_sh[slot], q);
     *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * o_ls * N + i) = r;
 }
+// grid (N/512, nl, X*npoly)
+__global__ __launch_bounds__(256) void k_lincomb(const ModC *__restrict__ mod, int N, LinComb lc, u64 *__restrict__ o,
+                                                 int npoly, int nl) {
+    const int j = blockIdx.y, xp = blockIdx.z, p = xp % npoly;
+    const ModC M = mod[j];
+    const size_t i = (size_t)j * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    u64 ax = 0, ay = 0;  // each term < q < 2^60 and at most 8 terms (+ c0): no overflow
+#pragma unroll
+    for (int t = 0; t < HY_LC_TERMS; t++)
+        if (t < lc.nterms) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lc.src[t] + (size_t)xp * lc.ls[t] * N + i);
+            ax += mulmod_shoup(v.x, lc.c[t][j], lc.cs[t][j], M.q);
+            ay += mulmod_shoup(v.y, lc.c[t][j], lc.cs[t][j], M.q);
+        }
+    if (p == 0) {
+        ax += lc.c0[j];
+        ay += lc.c0[j];
+    }
+    ulonglong2 r;
+    r.x = reduce64(ax, M);
+    r.y = reduce64(ay, M);
+    *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * nl * N + i) = r;
+}
 __global__ __launch_bounds__(256) void k_add_scalar(const ModC *__restrict__ mod, int N, u64 *__restrict__ a,
                                                     size_t outer, LimbSel sel, ScaleSel c) {
     const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n;
@@ -280,36 +303,41 @@ __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict_
 // acc[g][{d0,d1,d2}][j][c] = sum_{i<dim} rot[i] (x) db[g][i] with 128-bit lazy accumulation: one double-word
 // Barrett per output instead of 4*dim reductions.  45/46-bit limbs never overflow (dim * 2^93 < 2^128); the 60-bit
 // limb folds its accumulators every 64 diagonals.  16 B per lane per operand (1 KiB per wave instruction).
-// Each thread serves BPP database blocks with ONE read of the rotated query, and the block-group index is the
-// FASTEST grid dimension, so the workgroups that stream the same rot tile run together and share it through L2 /
-// Infinity Cache: HBM sees rot once instead of once per block.  grid (tiles * G/BPP, nl).
-template <int BPP>
-__global__ __launch_bounds__(256) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
-                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, int dim,
-                                                      int nl, int Gp) {
+//
+// Work split (HBM must see the 3 GiB of rotated queries ONCE, not once per block): a workgroup owns one 128-coefficient
+// tile of one limb and NW*BPP database blocks — each of its NW waves serves BPP blocks with one register copy of the
+// rot operands, and the NW waves read the SAME rot addresses in step (one barrier per diagonal), so the per-CU vector
+// cache serves NW-1 of them.  The database operands are streamed with non-temporal loads so they do not evict rot.
+// grid (256 tiles * G/(NW*BPP), nl), block group fastest.
+template <int BPP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
+                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, int dim,
+                                                          int nl, int Gq) {
     const int j = blockIdx.y;
-    const int gp = blockIdx.x % Gp, tile = blockIdx.x / Gp;
+    const int gq = blockIdx.x % Gq, tile = blockIdx.x / Gq;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ModC M = mod[j];
-    const size_t c = (size_t)(tile * 256 + threadIdx.x) * 2;
+    const size_t c = (size_t)tile * 128 + lane * 2;
     const size_t ps = (size_t)nl * N, cs = 2 * ps;  // poly stride, ciphertext stride
+    const int g0 = (gq * NW + wv) * BPP;
     const u64 *ra = rot + (size_t)j * N + c;
-    const u64 *da = db + (size_t)gp * BPP * dim * cs + (size_t)j * N + c;
+    const u64 *da = db + (size_t)g0 * dim * cs + (size_t)j * N + c;
     const size_t bs = (size_t)dim * cs;  // block stride
     const int kbits = M.ks + 2;
     const int chunk = (126 - 2 * kbits >= 30) ? dim : (1 << (126 - 2 * kbits));
     u128 d0x[BPP], d0y[BPP], d1x[BPP], d1y[BPP], d2x[BPP], d2y[BPP];
 #pragma unroll
     for (int u = 0; u < BPP; u++) d0x[u] = d0y[u] = d1x[u] = d1y[u] = d2x[u] = d2y[u] = 0;
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     for (int i0 = 0; i0 < dim; i0 += chunk) {
         const int i1 = i0 + chunk < dim ? i0 + chunk : dim;
-#pragma unroll 2
         for (int i = i0; i < i1; i++) {
             const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
             const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs + ps);
 #pragma unroll
             for (int u = 0; u < BPP; u++) {
-                const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(da + u * bs + (size_t)i * cs);
-                const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(da + u * bs + (size_t)i * cs + ps);
+                const ull2 b0 = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(da + u * bs + (size_t)i * cs));
+                const ull2 b1 = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(da + u * bs + (size_t)i * cs + ps));
                 d0x[u] += (u128)a0.x * b0.x;
                 d0y[u] += (u128)a0.y * b0.y;
                 d1x[u] += (u128)a0.x * b1.x + (u128)a1.x * b0.x;
@@ -317,6 +345,7 @@ __global__ __launch_bounds__(256) void k_hydia_tensor(const ModC *__restrict__ m
                 d2x[u] += (u128)a1.x * b1.x;
                 d2y[u] += (u128)a1.y * b1.y;
             }
+            if (NW > 1) __builtin_amdgcn_s_barrier();  // keep the waves on the same diagonal (no memory wait implied)
         }
         if (i1 < dim) {
 #pragma unroll
@@ -333,7 +362,7 @@ __global__ __launch_bounds__(256) void k_hydia_tensor(const ModC *__restrict__ m
         r0.x = reduce128(d0x[u], M); r0.y = reduce128(d0y[u], M);
         r1.x = reduce128(d1x[u], M); r1.y = reduce128(d1y[u], M);
         r2.x = reduce128(d2x[u], M); r2.y = reduce128(d2y[u], M);
-        u64 *o = acc + ((size_t)(gp * BPP + u) * 3 * nl + j) * N + c;
+        u64 *o = acc + ((size_t)(g0 + u) * 3 * nl + j) * N + c;
         *reinterpret_cast<ulonglong2 *>(o) = r0;
         *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
         *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
@@ -390,6 +419,9 @@ void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, in
                 const ScaleSel &c, int a_ls, int o_ls) {
     hipLaunchKernelGGL(k_mul_scalar, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, o, sel, c, a_ls, o_ls);
 }
+void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl) {
+    hipLaunchKernelGGL(k_lincomb, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, npoly, nl);
+}
 void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,
                 const ScaleSel &c) {
     hipLaunchKernelGGL(k_add_scalar, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, outer, sel, c);
@@ -422,15 +454,30 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
                      const ScaleSel &qlinv, int in_ls) {
     hipLaunchKernelGGL(k_rescale_combine, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, in, tmp, out, l, qlinv, in_ls);
 }
+template <int BPP, int NW>
+static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G, int dim,
+                          int nl) {
+    const int Gq = G / (BPP * NW);
+    hipLaunchKernelGGL((k_hydia_tensor<BPP, NW>), dim3((N / 128) * Gq, nl), dim3(64 * NW), 0, st, mod, N, rot, db, acc, dim, nl,
+                       Gq);
+}
+// bpp = database blocks per wave, nw = waves per workgroup (0: largest that divides); both must divide G
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
-                             int dim, int nl, int bpp) {
-    const int tiles = N / 512;
-    if (bpp >= 4 && G % 4 == 0)
-        hipLaunchKernelGGL(k_hydia_tensor<4>, dim3(tiles * (G / 4), nl), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl, G / 4);
-    else if (bpp >= 2 && G % 2 == 0)
-        hipLaunchKernelGGL(k_hydia_tensor<2>, dim3(tiles * (G / 2), nl), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl, G / 2);
-    else
-        hipLaunchKernelGGL(k_hydia_tensor<1>, dim3(tiles * G, nl), dim3(256), 0, st, mod, N, rot, db, acc, dim, nl, G);
+                             int dim, int nl, int bpp, int nw) {
+    int B = (bpp >= 4 && G % 4 == 0) ? 4 : (bpp >= 2 && G % 2 == 0) ? 2 : 1;
+    const int rest = G / B;
+    int W = 1;
+    for (int cand : {16, 8, 4, 2})
+        if ((nw == 0 || cand <= nw) && rest % cand == 0) {
+            W = cand;
+            break;
+        }
+#define HY_TENSOR_CASE(b, w) \
+    if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl);
+    HY_TENSOR_CASE(4, 16) HY_TENSOR_CASE(4, 8) HY_TENSOR_CASE(4, 4) HY_TENSOR_CASE(4, 2) HY_TENSOR_CASE(4, 1)
+    HY_TENSOR_CASE(2, 16) HY_TENSOR_CASE(2, 8) HY_TENSOR_CASE(2, 4) HY_TENSOR_CASE(2, 2) HY_TENSOR_CASE(2, 1)
+    HY_TENSOR_CASE(1, 16) HY_TENSOR_CASE(1, 8) HY_TENSOR_CASE(1, 4) HY_TENSOR_CASE(1, 2) HY_TENSOR_CASE(1, 1)
+#undef HY_TENSOR_CASE
 }
 const char *hydia_tensor_kernel_name() { return "k_hydia_tensor"; }
 void fill_uniform_hash(hipStream_t st, const ModC *mod, int N, u64 *dst, size_t n_limbpolys, int nl,

@@ -4,187 +4,307 @@
 // all 128 rows) then pass 2 (stages 7-14 inside 256-coefficient blocks: a workgroup owns 2048 consecutive
 // coefficients); the inverse runs pass 2' then pass 1' with Gentleman-Sande butterflies.  Butterflies run in REGISTERS
 // in radix-16 / radix-8 / radix-4 groups; LDS is used only to transpose between register phases (one exchange in
-// pass 1, two in pass 2, padded to be bank-conflict free for ds_read/write_b64).  Harvey lazy reduction keeps values in
-// [0,4q) (forward) / [0,2q) (inverse) and corrects once at the end, so results equal the strict transform bit for bit.
-// Pass-1 phase-A twiddles are workgroup-uniform (scalar loads); the remaining pass-1 twiddles sit in 2 KiB of LDS;
-// pass-2 twiddles are 16-byte (w, w') pair loads shared by the TWO polynomials a workgroup transforms together.
+// pass 1, two in pass 2, padded to be bank-conflict free for ds_read/write_b64).
+//
+// Two arithmetic back ends, chosen per limb (workgroup-uniform) and both EXACT, so results are bit-identical:
+//   IntA  64-bit integers, Shoup multiplication, Harvey lazy reduction ([0,4q) forward, [0,2q) inverse).  Used for the
+//         60-bit primes (q_0 and the special primes P).  ~10 32x32 multiplies + carry chains per butterfly.
+//   FpA   the 45/46-bit scaling primes fit a double's 53-bit mantissa: residues are kept as exact-integer doubles and
+//         a*w mod q is  h = a*w; l = fma(a,w,-h); c = rint(a*(w/q)); r = fma(-c,q,h) + l  — six FP64 instructions, no
+//         compares, no carries; the forward transform needs no reduction at all (growth <= 0.75q per stage, 15 stages
+//         stay below 2^50), the inverse re-centres once per register phase.  gfx950 issues FP64 FMA at least as fast
+//         as its 32x32 integer multiply, so this path is ~3x cheaper per butterfly.
+// Between the two passes FpA limbs travel as raw doubles in the (uint64) buffer; every limb leaves as canonical uint64.
+// Pass-1 phase-A twiddles are workgroup-uniform; the remaining pass-1 twiddles sit in 2 KiB of LDS; pass-2 twiddles are
+// 16-byte pair loads shared by the TWO polynomials a workgroup transforms together.
 #include "kernels.h"
 
 namespace {
 
-// lazy Cooley-Tukey butterfly: a, b in [0,4q) -> [0,4q)
-DEV void ct_bfly(u64 &a, u64 &b, const ulonglong2 W, const u64 q, const u64 q2) {
-    const u64 u = a >= q2 ? a - q2 : a;
-    const u64 hi = __umul64hi(b, W.y);
-    const u64 t = b * W.x - hi * q;  // [0,2q)
-    a = u + t;
-    b = u - t + q2;
-}
-// lazy Gentleman-Sande butterfly: a, b in [0,2q) -> [0,2q)
-DEV void gs_bfly(u64 &a, u64 &b, const ulonglong2 W, const u64 q, const u64 q2) {
-    u64 s = a + b;
-    s = s >= q2 ? s - q2 : s;
-    const u64 d = a - b + q2;
-    const u64 hi = __umul64hi(d, W.y);
-    b = d * W.x - hi * q;
-    a = s;
-}
-DEV u64 fix4q(u64 x, const u64 q, const u64 q2) {
-    x = x >= q2 ? x - q2 : x;
-    return x >= q ? x - q : x;
+struct IntA {
+    typedef u64 T;
+    typedef ulonglong2 TW;  // (w, floor(w 2^64 / q))
+    u64 q, q2;
+    DEV IntA(const ModC &M) : q(M.q), q2(2 * M.q) {}
+    DEV static TW tw(const ulonglong2 b) { return b; }
+    DEV T from_canon(u64 x) const { return x; }
+    DEV static T from_bits(u64 x) { return x; }
+    DEV static u64 to_bits(T x) { return x; }
+    DEV void ct(T &a, T &b, const TW W) const {  // [0,4q) -> [0,4q)
+        const u64 u = a >= q2 ? a - q2 : a;
+        const u64 hi = __umul64hi(b, W.y);
+        const u64 t = b * W.x - hi * q;
+        a = u + t;
+        b = u - t + q2;
+    }
+    DEV void gs(T &a, T &b, const TW W) const {  // [0,2q) -> [0,2q)
+        u64 s = a + b;
+        s = s >= q2 ? s - q2 : s;
+        const u64 d = a - b + q2;
+        const u64 hi = __umul64hi(d, W.y);
+        b = d * W.x - hi * q;
+        a = s;
+    }
+    DEV void recentre(T &) const {}
+    DEV u64 fin_fwd(T x) const {
+        x = x >= q2 ? x - q2 : x;
+        return x >= q ? x - q : x;
+    }
+    DEV u64 fin_inv(T x, u64 sc, u64 scs) const { return mulmod_shoup(x, sc, scs, q); }
+};
+
+struct FpA {
+    typedef double T;
+    typedef double2 TW;  // (w, w / q)
+    double q, qinv;
+    DEV FpA(const ModC &M) : q((double)M.q), qinv(1.0 / (double)M.q) {}
+    DEV static TW tw(const ulonglong2 b) { return make_double2(__longlong_as_double((long long)b.x), __longlong_as_double((long long)b.y)); }
+    DEV T from_canon(u64 x) const { return (double)(long long)x; }  // x < 2^47: exact
+    DEV static T from_bits(u64 x) { return __longlong_as_double((long long)x); }
+    DEV static u64 to_bits(T x) { return (u64)__double_as_longlong(x); }
+    DEV double mulmod(const double v, const TW W) const {  // exact v*w - c*q with |result| <= 0.75 q
+        const double h = v * W.x;
+        const double l = __fma_rn(v, W.x, -h);
+        const double c = rint(v * W.y);
+        return __fma_rn(-c, q, h) + l;
+    }
+    DEV void ct(T &a, T &b, const TW W) const {
+        const double r = mulmod(b, W);
+        b = a - r;
+        a = a + r;
+    }
+    DEV void gs(T &a, T &b, const TW W) const {
+        const double s = a + b, d = a - b;
+        b = mulmod(d, W);
+        a = s;
+    }
+    DEV void recentre(T &x) const { x = __fma_rn(-rint(x * qinv), q, x); }  // -> [-q/2, q/2]
+    DEV u64 fin_fwd(T x) const {
+        recentre(x);
+        if (x < 0) x += q;
+        return (u64)(long long)x;
+    }
+    DEV u64 fin_inv(T x, u64 sc, u64) const {
+        const double s = (double)(long long)sc;
+        double r = mulmod(x, make_double2(s, s * qinv));
+        if (r < 0) r += q;
+        return (u64)(long long)r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ fused prologues
+// canonical coefficient-form value of element `idx` (inside the limb-poly) of target limb `slot` for polynomial x
+template <int LD>
+DEV u64 p1_load(const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, const u64 *s, int x, int slot, size_t idx) {
+    if (LD == 0) return s[idx];
+    if (LD == 1) {  // fast base conversion: sum_s y_s[idx] * f[s][t], 128-bit lazy accumulation (ns <= 8, terms < 2^120)
+        const u64 *y = ld.y + (size_t)x * ld.y_outer + idx;
+        u128 acc = 0;
+#pragma unroll
+        for (int k = 0; k < HY_MAX_DIGIT; k++)
+            if (k < ld.tab.ns) acc += (u128)y[(size_t)k * 32768] * ld.tab.f[k][ld.t0 + slot];
+        return reduce128(acc, M);
+    }
+    // LD == 2: rescale spread: centred residue of the dropped limb's coefficient
+    const u64 ql = mod[ld.l].q, v = ld.y[(size_t)x * ld.y_outer + idx];
+    return v > (ql >> 1) ? negmod(reduce64(ql - v, M), M.q) : reduce64(v, M);
 }
 
 // ------------------------------------------------------------------------------------------------ pass 1 (strided)
-// grid (8 column tiles, X*sel.n), 256 threads: col = t&31, g = t>>5.  Phase A rows g+8k (k<16), phase B rows 8h+l.
-template <bool INV>
-__global__ __launch_bounds__(256) void k_ntt15_p1(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
-                                                  size_t dso, LimbSel sel, ScaleSel scale) {
-    constexpr int N = 32768;
-    __shared__ u64 lds[128 * 32];
-    __shared__ ulonglong2 ltw[128];
-    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n, m = sel.mod[slot];
-    const u64 q = T.mod[m].q, q2 = 2 * q;
-    const ulonglong2 *__restrict__ tw = (INV ? T.itwp : T.twp) + (size_t)m * N;
-    const u64 *s = src + (size_t)x * so + (size_t)slot * N + blockIdx.x * 32;
-    u64 *d = dst + (size_t)x * dso + (size_t)slot * N + blockIdx.x * 32;
-    const int t = threadIdx.x, col = t & 31, g = t >> 5;
-    if (t < 128) ltw[t] = tw[t];
-    u64 v[16];
+template <class A, bool INV, int LD>
+DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u64 *d, u64 *lds, const ulonglong2 *ltw, int t,
+                 u64 sc, u64 scs, const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, int x, int slot, int c0) {
+    typedef typename A::T T;
+    const int col = t & 31, g = t >> 5;
+    T v[16];
     if (!INV) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = s[(size_t)(g + 8 * k) * 256 + col];
+        for (int k = 0; k < 16; k++)
+            v[k] = ar.from_canon(p1_load<LD>(ld, mod, M, LD == 0 ? s : nullptr, x, slot,
+                                             (size_t)(g + 8 * k) * 256 + (LD == 0 ? 0 : c0) + col));
 #pragma unroll
         for (int st = 0; st < 4; st++) {
             const int h = 8 >> st;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (!(k & h)) ct_bfly(v[k], v[k + h], tw[(1 << st) + (k >> (4 - st))], q, q2);
+                if (!(k & h)) ar.ct(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) lds[(g + 8 * k) * 32 + col] = v[k];
+        for (int k = 0; k < 16; k++) lds[(g + 8 * k) * 32 + col] = A::to_bits(v[k]);
         __syncthreads();
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int h = g + 8 * hh;
-            u64 w[8];
+            T w[8];
 #pragma unroll
-            for (int l = 0; l < 8; l++) w[l] = lds[(8 * h + l) * 32 + col];
+            for (int l = 0; l < 8; l++) w[l] = A::from_bits(lds[(8 * h + l) * 32 + col]);
+            {
+                const typename A::TW W = A::tw(ltw[16 + h]);
 #pragma unroll
-            for (int l = 0; l < 4; l++) ct_bfly(w[l], w[l + 4], ltw[16 + h], q, q2);
+                for (int l = 0; l < 4; l++) ar.ct(w[l], w[l + 4], W);
+            }
 #pragma unroll
             for (int l = 0; l < 8; l++)
-                if (!(l & 2)) ct_bfly(w[l], w[l + 2], ltw[32 + 2 * h + (l >> 2)], q, q2);
+                if (!(l & 2)) ar.ct(w[l], w[l + 2], A::tw(ltw[32 + 2 * h + (l >> 2)]));
 #pragma unroll
-            for (int l = 0; l < 8; l += 2) ct_bfly(w[l], w[l + 1], ltw[64 + 4 * h + (l >> 1)], q, q2);
+            for (int l = 0; l < 8; l += 2) ar.ct(w[l], w[l + 1], A::tw(ltw[64 + 4 * h + (l >> 1)]));
 #pragma unroll
-            for (int l = 0; l < 8; l++) d[(size_t)(8 * h + l) * 256 + col] = w[l];  // lazy [0,4q): pass 2 finishes
+            for (int l = 0; l < 8; l++) d[(size_t)(8 * h + l) * 256 + col] = A::to_bits(w[l]);  // raw: pass 2 finishes
         }
     } else {
         __syncthreads();  // ltw
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int h = g + 8 * hh;
-            u64 w[8];
+            T w[8];
 #pragma unroll
-            for (int l = 0; l < 8; l++) w[l] = s[(size_t)(8 * h + l) * 256 + col];
+            for (int l = 0; l < 8; l++) w[l] = A::from_bits(s[(size_t)(8 * h + l) * 256 + col]);  // raw from pass 2'
 #pragma unroll
-            for (int l = 0; l < 8; l += 2) gs_bfly(w[l], w[l + 1], ltw[64 + 4 * h + (l >> 1)], q, q2);
+            for (int l = 0; l < 8; l += 2) ar.gs(w[l], w[l + 1], A::tw(ltw[64 + 4 * h + (l >> 1)]));
 #pragma unroll
             for (int l = 0; l < 8; l++)
-                if (!(l & 2)) gs_bfly(w[l], w[l + 2], ltw[32 + 2 * h + (l >> 2)], q, q2);
+                if (!(l & 2)) ar.gs(w[l], w[l + 2], A::tw(ltw[32 + 2 * h + (l >> 2)]));
+            {
+                const typename A::TW W = A::tw(ltw[16 + h]);
 #pragma unroll
-            for (int l = 0; l < 4; l++) gs_bfly(w[l], w[l + 4], ltw[16 + h], q, q2);
+                for (int l = 0; l < 4; l++) ar.gs(w[l], w[l + 4], W);
+            }
 #pragma unroll
-            for (int l = 0; l < 8; l++) lds[(8 * h + l) * 32 + col] = w[l];
+            for (int l = 0; l < 8; l++) {
+                ar.recentre(w[l]);
+                lds[(8 * h + l) * 32 + col] = A::to_bits(w[l]);
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[(g + 8 * k) * 32 + col];
+        for (int k = 0; k < 16; k++) v[k] = A::from_bits(lds[(g + 8 * k) * 32 + col]);
 #pragma unroll
         for (int st = 3; st >= 0; st--) {
             const int h = 8 >> st;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (!(k & h)) gs_bfly(v[k], v[k + h], tw[(1 << st) + (k >> (4 - st))], q, q2);
+                if (!(k & h)) ar.gs(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
         }
-        const u64 sc = scale.s[slot], scs = scale.s_sh[slot];
 #pragma unroll
-        for (int k = 0; k < 16; k++) d[(size_t)(g + 8 * k) * 256 + col] = mulmod_shoup(v[k], sc, scs, q);
+        for (int k = 0; k < 16; k++) d[(size_t)(g + 8 * k) * 256 + col] = ar.fin_inv(v[k], sc, scs);
+    }
+}
+
+// grid (8 column tiles, X*sel.n), 256 threads: col = t&31, g = t>>5.  Phase A rows g+8k (k<16), phase B rows 8h+l.
+template <bool INV, int LD>
+__global__ __launch_bounds__(256) void k_ntt15_p1(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
+                                                  size_t dso, LimbSel sel, ScaleSel scale, NttLoad ld) {
+    constexpr int N = 32768;
+    __shared__ u64 lds[128 * 32];
+    __shared__ ulonglong2 ltw[128];
+    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n, m = sel.mod[slot];
+    const ModC M = T.mod[m];
+    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
+    const int c0 = blockIdx.x * 32;
+    const u64 *s = src + (size_t)x * so + (size_t)slot * N + c0;
+    u64 *d = dst + (size_t)x * dso + (size_t)slot * N + c0;
+    const int t = threadIdx.x;
+    if (t < 128) ltw[t] = tw[t];
+    if (fp) p1_body<FpA, INV, LD>(FpA(M), tw, s, d, lds, ltw, t, scale.s[slot], scale.s_sh[slot], ld, T.mod, M, x, slot, c0);
+    else p1_body<IntA, INV, LD>(IntA(M), tw, s, d, lds, ltw, t, scale.s[slot], scale.s_sh[slot], ld, T.mod, M, x, slot, c0);
+}
+
+// ------------------------------------------------------------------------------------------------ fused epilogues
+DEV unsigned perm_idx(unsigned c, unsigned g) {  // evaluation-form automorphism index map for N = 2^15
+    const unsigned e = ((2u * (__brev(c) >> 17) + 1u) * g) & 65535u;
+    return __brev((e - 1u) >> 1) >> 17;
+}
+// v = canonical evaluation-form value of element idx of limb j (= slot) of polynomial xp
+template <int ST>
+DEV void p2_store(const NttStore &st, const ModC &M, u64 *d, int xp, int j, unsigned idx, u64 v) {
+    constexpr size_t N = 32768;
+    if (ST == 0) {
+        d[idx] = v;
+        return;
+    }
+    const u64 q = M.q;
+    const u64 iv = st.in[((size_t)xp * st.in_ls + j) * N + idx];
+    u64 r = mulmod_shoup(submod(iv, v, q), st.mul.s[j], st.mul.s_sh[j], q);
+    if (ST == 1) {
+        const int x = xp >> 1, p = xp & 1;
+        if (st.addend && p < st.add_polys) r = addmod(r, st.addend[(size_t)x * st.add_x + (size_t)p * st.add_p + (size_t)j * N + idx], q);
+        if (st.dbl) r = addmod(r, r, q);
+        unsigned o = idx;
+        if (st.ginv) {
+            const unsigned g = st.ginv[st.same_g ? 0 : x];
+            if (g != 1u) o = perm_idx(idx, g);
+        }
+        st.out[((size_t)xp * st.nl + j) * N + o] = r;
+    } else {
+        if (st.sub) r = submod(r, st.sub[((size_t)xp * st.sub_ls + j) * N + idx], q);
+        if (st.has_addc && (xp % st.npoly) == 0) r = addmod(r, st.addc[j], q);
+        st.out[((size_t)xp * st.nl + j) * N + idx] = r;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2 (contiguous)
-// grid (16 chunks of 2048, pairs), 256 threads: blk = t>>5, w = t&31.  NP polynomials (1 or 2, same modulus) share every
-// twiddle load.  LDS rows of 32 coefficients are padded to 36 so phase B's (a, b) reads hit 64 distinct banks.
-template <bool INV, int NP>
-__global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
-                                                  size_t dso, LimbSel sel) {
-    constexpr int N = 32768, LROW = 36, LBLK = 8 * LROW;
-    __shared__ u64 lds[NP][8 * LBLK];
-    const int y = blockIdx.y;
-    const int xp = y / sel.n, slot = y - xp * sel.n, m = sel.mod[slot];
-    const u64 q = T.mod[m].q, q2 = 2 * q;
-    const ulonglong2 *__restrict__ tw = (INV ? T.itwp : T.twp) + (size_t)m * N;
-    const int B0 = blockIdx.x * 2048, t = threadIdx.x, blk = t >> 5, w = t & 31;
+// 256 threads: blk = t>>5, w = t&31.  NP polynomials (1 or 2, same modulus) share every twiddle load.  LDS rows of 32
+// coefficients are padded to 36 so phase B's (a, b) reads hit 64 distinct banks.
+template <class A, bool INV, int NP, int ST>
+DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const *s, u64 *const *d, u64 (*lds)[8 * 288], int t,
+                 int B0, const NttStore &stp, const ModC &M, int xp0, int slot) {
+    typedef typename A::T T;
+    typedef typename A::TW TW;
+    constexpr int LROW = 36, LBLK = 8 * LROW;
+    const int blk = t >> 5, w = t & 31;
     const int bg = (B0 >> 8) + blk;
     const int a = w >> 2, b = w & 3;
-    const u64 *s[NP];
-    u64 *d[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;
-        d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;
-    }
-    u64 v[NP][8];
+    T v[NP][8];
     if (!INV) {
         // phase A: coefficients blk*256 + 32k + w ; stages 7,8,9 (strides 128, 64, 32)
 #pragma unroll
         for (int p = 0; p < NP; p++)
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[p][k] = s[p][blk * 256 + 32 * k + w];
+            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(s[p][blk * 256 + 32 * k + w]);  // raw from pass 1
         {
-            const ulonglong2 W7 = tw[128 + bg];
-            const ulonglong2 W8a = tw[256 + 2 * bg], W8b = tw[256 + 2 * bg + 1];
-            ulonglong2 W9[4];
+            const TW W7 = A::tw(tw[128 + bg]);
+            const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
+            TW W9[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) W9[i] = tw[512 + 4 * bg + i];
+            for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) ct_bfly(v[p][k], v[p][k + 4], W7, q, q2);
-                ct_bfly(v[p][0], v[p][2], W8a, q, q2);
-                ct_bfly(v[p][1], v[p][3], W8a, q, q2);
-                ct_bfly(v[p][4], v[p][6], W8b, q, q2);
-                ct_bfly(v[p][5], v[p][7], W8b, q, q2);
+                for (int k = 0; k < 4; k++) ar.ct(v[p][k], v[p][k + 4], W7);
+                ar.ct(v[p][0], v[p][2], W8a);
+                ar.ct(v[p][1], v[p][3], W8a);
+                ar.ct(v[p][4], v[p][6], W8b);
+                ar.ct(v[p][5], v[p][7], W8b);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) ct_bfly(v[p][k], v[p][k + 1], W9[k >> 1], q, q2);
+                for (int k = 0; k < 8; k += 2) ar.ct(v[p][k], v[p][k + 1], W9[k >> 1]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + k * LROW + w] = v[p][k];
+                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + k * LROW + w] = A::to_bits(v[p][k]);
             }
         }
         __syncthreads();
         // phase B: coefficients blk*256 + 32a + 4k + b ; stages 10,11,12 (strides 16, 8, 4)
         {
             const int ib = 8 * bg + a;
-            const ulonglong2 W10 = tw[1024 + ib];
-            const ulonglong2 W11a = tw[2048 + 2 * ib], W11b = tw[2048 + 2 * ib + 1];
-            ulonglong2 W12[4];
+            const TW W10 = A::tw(tw[1024 + ib]);
+            const TW W11a = A::tw(tw[2048 + 2 * ib]), W11b = A::tw(tw[2048 + 2 * ib + 1]);
+            TW W12[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) W12[i] = tw[4096 + 4 * ib + i];
+            for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[p][k] = lds[p][blk * LBLK + a * LROW + 4 * k + b];
+                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + a * LROW + 4 * k + b]);
 #pragma unroll
-                for (int k = 0; k < 4; k++) ct_bfly(v[p][k], v[p][k + 4], W10, q, q2);
-                ct_bfly(v[p][0], v[p][2], W11a, q, q2);
-                ct_bfly(v[p][1], v[p][3], W11a, q, q2);
-                ct_bfly(v[p][4], v[p][6], W11b, q, q2);
-                ct_bfly(v[p][5], v[p][7], W11b, q, q2);
+                for (int k = 0; k < 4; k++) ar.ct(v[p][k], v[p][k + 4], W10);
+                ar.ct(v[p][0], v[p][2], W11a);
+                ar.ct(v[p][1], v[p][3], W11a);
+                ar.ct(v[p][4], v[p][6], W11b);
+                ar.ct(v[p][5], v[p][7], W11b);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) ct_bfly(v[p][k], v[p][k + 1], W12[k >> 1], q, q2);
+                for (int k = 0; k < 8; k += 2) ar.ct(v[p][k], v[p][k + 1], W12[k >> 1]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + a * LROW + 4 * k + b] = v[p][k];
+                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
             }
         }
         __syncthreads();
@@ -193,19 +313,28 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
         for (int hh = 0; hh < 2; hh++) {
             const int e = 4 * t + 1024 * hh, u = e & 255, la = (e >> 8) * LBLK + (u >> 5) * LROW + (u & 31);
             const int gi = (B0 + e) >> 2;
-            const ulonglong2 W13 = tw[8192 + gi], W14a = tw[16384 + 2 * gi], W14b = tw[16384 + 2 * gi + 1];
+            const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                u64 c0 = lds[p][la], c1 = lds[p][la + 1], c2 = lds[p][la + 2], c3 = lds[p][la + 3];
-                ct_bfly(c0, c2, W13, q, q2);
-                ct_bfly(c1, c3, W13, q, q2);
-                ct_bfly(c0, c1, W14a, q, q2);
-                ct_bfly(c2, c3, W14b, q, q2);
-                ulonglong2 o0, o1;
-                o0.x = fix4q(c0, q, q2); o0.y = fix4q(c1, q, q2);
-                o1.x = fix4q(c2, q, q2); o1.y = fix4q(c3, q, q2);
-                *reinterpret_cast<ulonglong2 *>(d[p] + e) = o0;
-                *reinterpret_cast<ulonglong2 *>(d[p] + e + 2) = o1;
+                T c0 = A::from_bits(lds[p][la]), c1 = A::from_bits(lds[p][la + 1]), c2 = A::from_bits(lds[p][la + 2]),
+                  c3 = A::from_bits(lds[p][la + 3]);
+                ar.ct(c0, c2, W13);
+                ar.ct(c1, c3, W13);
+                ar.ct(c0, c1, W14a);
+                ar.ct(c2, c3, W14b);
+                if (ST == 0) {
+                    ulonglong2 o0, o1;
+                    o0.x = ar.fin_fwd(c0); o0.y = ar.fin_fwd(c1);
+                    o1.x = ar.fin_fwd(c2); o1.y = ar.fin_fwd(c3);
+                    *reinterpret_cast<ulonglong2 *>(d[p] + e) = o0;
+                    *reinterpret_cast<ulonglong2 *>(d[p] + e + 2) = o1;
+                } else {
+                    const unsigned idx = (unsigned)(B0 + e);
+                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx, ar.fin_fwd(c0));
+                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx + 1, ar.fin_fwd(c1));
+                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx + 2, ar.fin_fwd(c2));
+                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx + 3, ar.fin_fwd(c3));
+                }
             }
         }
     } else {
@@ -214,92 +343,147 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
         for (int hh = 0; hh < 2; hh++) {
             const int e = 4 * t + 1024 * hh, u = e & 255, la = (e >> 8) * LBLK + (u >> 5) * LROW + (u & 31);
             const int gi = (B0 + e) >> 2;
-            const ulonglong2 W13 = tw[8192 + gi], W14a = tw[16384 + 2 * gi], W14b = tw[16384 + 2 * gi + 1];
+            const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const ulonglong2 i0 = *reinterpret_cast<const ulonglong2 *>(s[p] + e);
                 const ulonglong2 i1 = *reinterpret_cast<const ulonglong2 *>(s[p] + e + 2);
-                u64 c0 = i0.x, c1 = i0.y, c2 = i1.x, c3 = i1.y;
-                gs_bfly(c0, c1, W14a, q, q2);
-                gs_bfly(c2, c3, W14b, q, q2);
-                gs_bfly(c0, c2, W13, q, q2);
-                gs_bfly(c1, c3, W13, q, q2);
-                lds[p][la] = c0; lds[p][la + 1] = c1; lds[p][la + 2] = c2; lds[p][la + 3] = c3;
+                T c0 = ar.from_canon(i0.x), c1 = ar.from_canon(i0.y), c2 = ar.from_canon(i1.x), c3 = ar.from_canon(i1.y);
+                ar.gs(c0, c1, W14a);
+                ar.gs(c2, c3, W14b);
+                ar.gs(c0, c2, W13);
+                ar.gs(c1, c3, W13);
+                ar.recentre(c0); ar.recentre(c1); ar.recentre(c2); ar.recentre(c3);
+                lds[p][la] = A::to_bits(c0); lds[p][la + 1] = A::to_bits(c1);
+                lds[p][la + 2] = A::to_bits(c2); lds[p][la + 3] = A::to_bits(c3);
             }
         }
         __syncthreads();
         // phase B': strides 4, 8, 16
         {
             const int ib = 8 * bg + a;
-            const ulonglong2 W10 = tw[1024 + ib];
-            const ulonglong2 W11a = tw[2048 + 2 * ib], W11b = tw[2048 + 2 * ib + 1];
-            ulonglong2 W12[4];
+            const TW W10 = A::tw(tw[1024 + ib]);
+            const TW W11a = A::tw(tw[2048 + 2 * ib]), W11b = A::tw(tw[2048 + 2 * ib + 1]);
+            TW W12[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) W12[i] = tw[4096 + 4 * ib + i];
+            for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[p][k] = lds[p][blk * LBLK + a * LROW + 4 * k + b];
+                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + a * LROW + 4 * k + b]);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) gs_bfly(v[p][k], v[p][k + 1], W12[k >> 1], q, q2);
-                gs_bfly(v[p][0], v[p][2], W11a, q, q2);
-                gs_bfly(v[p][1], v[p][3], W11a, q, q2);
-                gs_bfly(v[p][4], v[p][6], W11b, q, q2);
-                gs_bfly(v[p][5], v[p][7], W11b, q, q2);
+                for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W12[k >> 1]);
+                ar.gs(v[p][0], v[p][2], W11a);
+                ar.gs(v[p][1], v[p][3], W11a);
+                ar.gs(v[p][4], v[p][6], W11b);
+                ar.gs(v[p][5], v[p][7], W11b);
 #pragma unroll
-                for (int k = 0; k < 4; k++) gs_bfly(v[p][k], v[p][k + 4], W10, q, q2);
+                for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W10);
 #pragma unroll
-                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + a * LROW + 4 * k + b] = v[p][k];
+                for (int k = 0; k < 8; k++) {
+                    ar.recentre(v[p][k]);
+                    lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
+                }
             }
         }
         __syncthreads();
         // phase A': strides 32, 64, 128
         {
-            const ulonglong2 W7 = tw[128 + bg];
-            const ulonglong2 W8a = tw[256 + 2 * bg], W8b = tw[256 + 2 * bg + 1];
-            ulonglong2 W9[4];
+            const TW W7 = A::tw(tw[128 + bg]);
+            const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
+            TW W9[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) W9[i] = tw[512 + 4 * bg + i];
+            for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[p][k] = lds[p][blk * LBLK + k * LROW + w];
+                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + k * LROW + w]);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) gs_bfly(v[p][k], v[p][k + 1], W9[k >> 1], q, q2);
-                gs_bfly(v[p][0], v[p][2], W8a, q, q2);
-                gs_bfly(v[p][1], v[p][3], W8a, q, q2);
-                gs_bfly(v[p][4], v[p][6], W8b, q, q2);
-                gs_bfly(v[p][5], v[p][7], W8b, q, q2);
+                for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W9[k >> 1]);
+                ar.gs(v[p][0], v[p][2], W8a);
+                ar.gs(v[p][1], v[p][3], W8a);
+                ar.gs(v[p][4], v[p][6], W8b);
+                ar.gs(v[p][5], v[p][7], W8b);
 #pragma unroll
-                for (int k = 0; k < 4; k++) gs_bfly(v[p][k], v[p][k + 4], W7, q, q2);
+                for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W7);
 #pragma unroll
-                for (int k = 0; k < 8; k++) d[p][blk * 256 + 32 * k + w] = v[p][k];  // lazy [0,2q): pass 1' finishes
+                for (int k = 0; k < 8; k++) {
+                    ar.recentre(v[p][k]);
+                    d[p][blk * 256 + 32 * k + w] = A::to_bits(v[p][k]);  // raw: pass 1' finishes
+                }
             }
         }
     }
+}
+
+// grid (16 chunks of 2048, (X/NP)*sel.n)
+template <bool INV, int NP, int ST>
+__global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
+                                                  size_t dso, LimbSel sel, NttStore stp) {
+    constexpr int N = 32768;
+    __shared__ u64 lds[NP][8 * 288];
+    const int y = blockIdx.y;
+    const int xp = y / sel.n, slot = y - xp * sel.n, m = sel.mod[slot];
+    const ModC M = T.mod[m];
+    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
+    const int B0 = blockIdx.x * 2048;
+    const u64 *s[NP];
+    u64 *d[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;
+        d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;
+    }
+    if (fp) p2_body<FpA, INV, NP, ST>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    else p2_body<IntA, INV, NP, ST>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
 }
 
 }  // namespace
 
 namespace hk {
 
+template <int LD>
+static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
+                          const LimbSel &sel, const NttLoad &ld) {
+    ScaleSel dummy = {};
+    hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, dummy, ld);
+}
+template <int ST>
+static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel,
+                          const NttStore &stp) {
+    if (X % 2 == 0)
+        hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, stp);
+    else
+        hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, stp);
+}
+
 // element (x, slot) at base + x*outer + slot*N.  When X is even, pass 2 transforms polynomials 2x', 2x'+1 together.
 void ntt15_forward(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                    const LimbSel &sel) {
-    ScaleSel dummy = {};
-    hipLaunchKernelGGL(k_ntt15_p1<false>, dim3(8, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, dummy);
-    if (X % 2 == 0)
-        hipLaunchKernelGGL((k_ntt15_p2<false, 2>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel);
-    else
-        hipLaunchKernelGGL((k_ntt15_p2<false, 1>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel);
+    NttLoad ld{};
+    NttStore stp{};
+    launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
+    launch_p2_fwd<0>(st, T, dst, dso, X, sel, stp);
+}
+void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
+                         const LimbSel &sel, const NttLoad &ld, const NttStore &stp) {
+    if (ld.mode == 1) launch_p1_fwd<1>(st, T, src, dst, so, dso, X, sel, ld);
+    else if (ld.mode == 2) launch_p1_fwd<2>(st, T, src, dst, so, dso, X, sel, ld);
+    else launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
+    if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, stp);
+    else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, stp);
+    else launch_p2_fwd<0>(st, T, dst, dso, X, sel, stp);
 }
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                    const LimbSel &sel, const ScaleSel &scale) {
+    NttLoad ld{};
+    NttStore stp{};
     if (X % 2 == 0)
-        hipLaunchKernelGGL((k_ntt15_p2<true, 2>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel);
+        hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, stp);
     else
-        hipLaunchKernelGGL((k_ntt15_p2<true, 1>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel);
-    hipLaunchKernelGGL(k_ntt15_p1<true>, dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, scale);
+        hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, stp);
+    hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, scale, ld);
 }
 
 }  // namespace hk
