@@ -307,6 +307,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     if (getenv("HYDIA_NTT_INT")) tabs.twf = tabs.itwf = nullptr;  // A/B switch: integer butterflies for every limb
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
+    fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
     HIP_CHECK(hipMalloc((void **)&d_rotptrs, sizeof(u64 *) * (size_t)p.dim));
     HIP_CHECK(hipMalloc((void **)&d_rotgalois, sizeof(unsigned) * (size_t)p.dim));
     HIP_CHECK(hipMalloc((void **)&d_rotginv, sizeof(unsigned) * (size_t)p.dim));

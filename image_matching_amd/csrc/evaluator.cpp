@@ -62,8 +62,10 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
         LimbSel rest{};
         rest.n = nE - hi;
         for (int t = hi; t < nE; t++) rest.mod[t - hi] = esel.mod[t];
-        if (prm.logN == 15) {
-            // base conversion fused into the forward NTT's first pass: the converted residues never touch HBM
+        if (prm.logN == 15 && fuse_bconv) {
+            // (experiment switch HYDIA_FUSE_BCONV) base conversion fused into the forward NTT's first pass: measured
+            // SLOWER than the separate all-targets kernel (16.8 vs 14.2 ms per 2^20 query: every target limb re-reads
+            // the sources with 8-byte loads and pays its own 128-bit reduction), so it is off by default
             NttLoad ld{};
             ld.mode = 1;
             ld.y = y;
@@ -113,14 +115,18 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     const LimbSel qsel = sel_q(nl);
     std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
     if (prm.logN == 15) {
-        // P -> Q base conversion fused into the NTT's first pass, ModDown combine (+ addend, doubling, automorphism
-        // scatter) fused into its second pass: `conv` is only the inter-pass scratch
+        // ModDown combine (+ addend, doubling, automorphism scatter) fused into the NTT's second pass; the P -> Q base
+        // conversion runs as its own all-targets kernel unless HYDIA_FUSE_BCONV asks for the first-pass fusion
         NttLoad ld{};
-        ld.mode = 1;
-        ld.y = y;
-        ld.y_outer = (size_t)nP * N;
-        ld.tab = tab;
-        ld.t0 = 0;
+        if (fuse_bconv) {
+            ld.mode = 1;
+            ld.y = y;
+            ld.y_outer = (size_t)nP * N;
+            ld.tab = tab;
+            ld.t0 = 0;
+        } else {
+            hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
+        }
         NttStore stp{};
         stp.mode = 1;
         stp.out = out;
@@ -135,7 +141,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
         stp.dbl = dbl ? 1 : 0;
         stp.ginv = d_ginv;
         stp.same_g = same_galois;
-        hk::ntt15_forward_fused(stream, tabs, nullptr, conv, 0, (size_t)nl * N, X * 2, qsel, ld, stp);
+        hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, X * 2, qsel, ld, stp);
     } else {
         hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
         ntt_fwd(conv, (size_t)nl * N, X * 2, qsel);

@@ -150,7 +150,8 @@ struct Context : HostParams {
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
     int tensor_bpp = 4;             // DB blocks per wave in loop B (HYDIA_TENSOR_BPP)
-    int tensor_nw = 0;              // waves per workgroup in loop B, 0 = as many as divide (HYDIA_TENSOR_NW)             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
+    int tensor_nw = 4;              // max waves per workgroup in loop B (HYDIA_TENSOR_NW; 0 = up to 16)
+    bool fuse_bconv = false;        // HYDIA_FUSE_BCONV: base conversion inside the NTT's first pass (slower, kept for A/B)             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
     void add_inplace(Ct &a, const Ct &b);
     void sub_inplace(Ct &a, const Ct &b);
     void add_const(Ct &a, double c);

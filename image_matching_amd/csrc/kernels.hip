@@ -312,9 +312,13 @@ __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict_
 template <int BPP, int NW>
 __global__ __launch_bounds__(64 * NW) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
                                                           const u64 *__restrict__ db, u64 *__restrict__ acc, int dim,
-                                                          int nl, int Gq) {
+                                                          int nl, int Gq, int xcd_map) {
     const int j = blockIdx.y;
-    const int gq = blockIdx.x % Gq, tile = blockIdx.x / Gq;
+    // consecutive workgroup ids are dealt round-robin over the 8 XCDs: give every XCD its own tiles and let the Gq block
+    // groups of one tile follow each other ON THAT XCD, so they find the tile's rot lines in its L2
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int gq = xcd_map ? k % Gq : blockIdx.x % Gq;
+    const int tile = xcd_map ? xcd + 8 * (k / Gq) : blockIdx.x / Gq;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ModC M = mod[j];
     const size_t c = (size_t)tile * 128 + lane * 2;
@@ -458,8 +462,9 @@ template <int BPP, int NW>
 static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G, int dim,
                           int nl) {
     const int Gq = G / (BPP * NW);
+    static const int xcd_map = getenv("HYDIA_TENSOR_NOXCD") ? 0 : 1;
     hipLaunchKernelGGL((k_hydia_tensor<BPP, NW>), dim3((N / 128) * Gq, nl), dim3(64 * NW), 0, st, mod, N, rot, db, acc, dim, nl,
-                       Gq);
+                       Gq, (N / 128) % 8 == 0 ? xcd_map : 0);
 }
 // bpp = database blocks per wave, nw = waves per workgroup (0: largest that divides); both must divide G
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
