@@ -181,12 +181,15 @@ def main():
                                    % (args.log2n, G, G * dim * 2 * cc.nQ * cc.N * 8 / 2 ** 30),
                        "db_vectors_total": world * n, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3", "sharding": "row-block per GPU, RCCL gather of results",
+                       "db_storage": "%.1f GiB resident (45/46-bit limbs held as 48-bit residues)" % (cc.db_stats()[2] / 2 ** 30),
                        "result_check": "decrypted index == planted matches" if not args.random_db else "skipped (random DB)",
                        "result_correct": bool(correct), "setup_s": {"keygen": round(t_keygen, 2), "enroll": round(t_enroll, 2)}},
             "roofline": {"kernel": "k_hydia_tensor", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches": int(launches)},
+                         "launches": int(launches),
+                         "note": "algorithmic bytes = SURVEY 8d figure (196608 B per DB vector at 8 B per residue) + rotated queries + "
+                                 "accumulators; one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two kernels)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -1,4 +1,5 @@
 // image_matching_amd/csrc/capi.cpp — the extern "C" boundary of libhydia.so (include/hydia.h).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -338,7 +339,7 @@ size_t hydia_db_num_cts(const hydia_ctx *ctx, size_t n) {
     return ((nblk + per - 1) / per) * dim;
 }
 static void db_alloc(Context &cx, size_t n_vectors, size_t cts) {
-    const size_t bytes = cts * 2 * cx.nQ * cx.N * sizeof(u64);
+    const size_t bytes = cts * cx.db_layout().ct_bytes;
     if (cx.d_db && cx.db_cts != cts) {
         cx.sync();
         HIP_CHECK(hipFree(cx.d_db));
@@ -362,8 +363,12 @@ int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data) {
     if (!cx.d_db) return fail(HYDIA_ERR_STATE, "hydia: no database resident (call hydia_db_alloc)");
     REQUIRE(t < cx.db_cts, "ciphertext index out of range");
     const size_t e = (size_t)2 * cx.nQ * cx.N;
+    u64 *tmp = cx.pool.get(e * sizeof(u64));
     cx.sync();
-    HIP_CHECK(hipMemcpy(cx.d_db + t * e, data, e * sizeof(u64), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(tmp, data, e * sizeof(u64), hipMemcpyHostToDevice));
+    cx.db_store(t, tmp, 1);
+    cx.sync();
+    cx.pool.put(tmp);
     return HYDIA_OK;
     API_END
 }
@@ -374,8 +379,11 @@ int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data) {
     if (!cx.d_db) return fail(HYDIA_ERR_STATE, "hydia: no database resident");
     REQUIRE(t < cx.db_cts, "ciphertext index out of range");
     const size_t e = (size_t)2 * cx.nQ * cx.N;
+    u64 *tmp = cx.pool.get(e * sizeof(u64));
+    cx.db_fetch(t, tmp, 1);
     cx.sync();
-    HIP_CHECK(hipMemcpy(data, cx.d_db + t * e, e * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(data, tmp, e * sizeof(u64), hipMemcpyDeviceToHost));
+    cx.pool.put(tmp);
     return HYDIA_OK;
     API_END
 }
@@ -385,8 +393,15 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     Context &cx = ctx->cx;
     const size_t cts = hydia_db_num_cts(ctx, n_vectors);
     db_alloc(cx, n_vectors, cts);
-    hk::fill_uniform_hash(cx.stream, cx.d_mod, cx.N, cx.d_db, cts * 2 * cx.nQ, cx.nQ, seed);
+    const size_t chunk = (size_t)cx.prm.dim, e = (size_t)2 * cx.nQ * cx.N;
+    u64 *tmp = cx.pool.get(chunk * e * sizeof(u64));
+    for (size_t t0 = 0; t0 < cts; t0 += chunk) {
+        const size_t cnt = std::min(chunk, cts - t0);
+        hk::fill_uniform_hash(cx.stream, cx.d_mod, cx.N, tmp, cnt * 2 * cx.nQ, cx.nQ, seed + 0x9E37ull * t0);
+        cx.db_store(t0, tmp, (int)cnt);
+    }
     cx.sync();
+    cx.pool.put(tmp);
     return HYDIA_OK;
     API_END
 }
@@ -403,7 +418,7 @@ int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_
     REQUIRE(ctx, "null ctx");
     if (n_vectors) *n_vectors = ctx->cx.db_vectors;
     if (n_cts) *n_cts = ctx->cx.db_cts;
-    if (bytes) *bytes = ctx->cx.db_cts * 2 * ctx->cx.nQ * ctx->cx.N * sizeof(u64);
+    if (bytes) *bytes = ctx->cx.db_cts * ctx->cx.db_layout().ct_bytes;
     return HYDIA_OK;
 }
 

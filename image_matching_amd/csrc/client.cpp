@@ -197,15 +197,18 @@ void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]) {
     const size_t G = cx.db_cts / dim, ct_elems = (size_t)2 * cx.nQ * cx.N;
     double *d_rows = (double *)cx.pool.get(sizeof(double) * (size_t)Nh * dim);
     double *d_slots = (double *)cx.pool.get(sizeof(double) * (size_t)dim * Nh);
+    u64 *d_cts = cx.pool.get(sizeof(u64) * (size_t)dim * ct_elems);  // one group of fresh ciphertexts before packing
     for (size_t g = 0; g < G; g++) {
         const size_t first = g * (size_t)Nh;
         const size_t rows = n > first ? std::min((size_t)Nh, n - first) : 0;
         if (rows)
             HIP_CHECK(hipMemcpyAsync(d_rows, db + first * dim, sizeof(double) * rows * dim, hipMemcpyHostToDevice, cx.stream));
         hc::diag_pack(cx.stream, d_rows, (long long)rows, dim, Nh, d_slots);
-        encrypt_device(cx, d_slots, dim, key, HY_DB_NONCE_BASE + g * dim, cx.d_db + g * dim * ct_elems);
+        encrypt_device(cx, d_slots, dim, key, HY_DB_NONCE_BASE + g * dim, d_cts);
+        cx.db_store(g * dim, d_cts, dim);
     }
     cx.sync();
+    cx.pool.put(d_cts);
     cx.pool.put((u64 *)d_slots);
     cx.pool.put((u64 *)d_rows);
 }

@@ -308,6 +308,9 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
     fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
+    db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
+    for (int j = 1; j < nQ; j++)
+        if (q[j] >> 48) db_packed = false;
     HIP_CHECK(hipMalloc((void **)&d_rotptrs, sizeof(u64 *) * (size_t)p.dim));
     HIP_CHECK(hipMalloc((void **)&d_rotgalois, sizeof(unsigned) * (size_t)p.dim));
     HIP_CHECK(hipMalloc((void **)&d_rotginv, sizeof(unsigned) * (size_t)p.dim));
@@ -400,6 +403,14 @@ void Context::load_eval_key(int rot, const u64 *host) {
     u64 *dst = eval_key_storage(rot);
     sync();
     HIP_CHECK(hipMemcpy(dst, host, (size_t)prm.dnum * 2 * nT * N * sizeof(u64), hipMemcpyHostToDevice));
+}
+
+// ------------------------------------------------------------------ resident database
+void Context::db_store(size_t t0, const u64 *d_plain, int X) {
+    hk::db_pack(stream, N, nQ, d_plain, d_db + t0 * db_layout().ct_bytes, X, db_packed ? 1 : 0);
+}
+void Context::db_fetch(size_t t0, u64 *d_plain, int X) {
+    hk::db_unpack(stream, N, nQ, d_plain, d_db + t0 * db_layout().ct_bytes, X, db_packed ? 1 : 0);
 }
 
 // ------------------------------------------------------------------ kernel timers

@@ -347,7 +347,7 @@ Ct Context::similarity(const Ct &qc) {
     Ct rot = rotate_query(qc);
     Ct acc(this, G, 3, nQ, qc.scale * delta);
     timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw);
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
     timer_end("hydia_tensor");
     relinearize(acc);
     rescale(acc);

@@ -115,9 +115,14 @@ struct Context : HostParams {
     unsigned *d_rot_group = nullptr;   // canonical embedding: 5^j mod 2N
     double *d_ksi = nullptr;           // (cos, sin)(2 pi k / 2N), k <= 2N
 
-    // encrypted database resident in HBM: [G*dim][2][nQ][N]
-    u64 *d_db = nullptr;
+    // encrypted database resident in HBM: G*dim ciphertexts in the DbLayout of kernels.h (45/46-bit limbs stored as
+    // 48-bit residues when every scaling prime is below 2^48; HYDIA_DB_UNPACKED keeps plain [2][nQ][N] u64)
+    unsigned char *d_db = nullptr;
     size_t db_vectors = 0, db_cts = 0;
+    bool db_packed = true;
+    DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }
+    void db_store(size_t t0, const u64 *d_plain, int X);  // [X][2][nQ][N] device residues -> ciphertexts t0..t0+X-1
+    void db_fetch(size_t t0, u64 *d_plain, int X);
 
     std::map<std::string, KernelTimer> timers;
     bool timing = true;
@@ -149,7 +154,7 @@ struct Context : HostParams {
     void rescale(Ct &c, const Ct *sub = nullptr, const double *addc = nullptr);
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
-    int tensor_bpp = 4;             // DB blocks per wave in loop B (HYDIA_TENSOR_BPP)
+    int tensor_bpp = 2;             // DB blocks per wave in loop B (HYDIA_TENSOR_BPP; 4 spills past 168 VGPRs)
     int tensor_nw = 4;              // max waves per workgroup in loop B (HYDIA_TENSOR_NW; 0 = up to 16)
     bool fuse_bconv = false;        // HYDIA_FUSE_BCONV: base conversion inside the NTT's first pass (slower, kept for A/B)             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
     void add_inplace(Ct &a, const Ct &b);

@@ -75,7 +75,17 @@ struct NttStore {
 };
 
 
+// resident database layout: ciphertext t at t*ct_bytes, polynomial p at + p*poly_bytes, limb 0 as N 8-byte residues, then
+// (packed) limbs 1.. as N 6-byte residues each — or plain [2][nQ][N] u64 when not packed
+struct DbLayout {
+    unsigned long long ct_bytes, poly_bytes;
+    int packed;
+};
+
 namespace hk {
+DbLayout db_layout(int N, int nQ, int packed);
+void db_pack(hipStream_t st, int N, int nQ, const u64 *plain /* [X][2][nQ][N] */, void *db, int X, int packed);
+void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, int X, int packed);
 
 // ---- NTT: X limb-polys of N coefficients; element (x, slot) lives at base + x*outer + slot*N, slot < sel.n
 void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t src_outer,
@@ -130,8 +140,8 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
                      const ScaleSel &qlinv, int in_ls);
 
 // ---- loop B of the HyDia sender: acc[g][3][nl][N] = sum_i rot[i] (x) db[g][i], fully reduced
-void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
-                             int dim, int nl, int bpp, int nw);
+void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
+                             int dim, int nl, int bpp, int nw, int packed);
 const char *hydia_tensor_kernel_name();
 
 // ---- misc

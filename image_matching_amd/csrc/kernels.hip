@@ -309,11 +309,37 @@ __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict_
 // rot operands, and the NW waves read the SAME rot addresses in step (one barrier per diagonal), so the per-CU vector
 // cache serves NW-1 of them.  The database operands are streamed with non-temporal loads so they do not evict rot.
 // grid (256 tiles * G/(NW*BPP), nl), block group fastest.
-template <int BPP, int NW>
-__global__ __launch_bounds__(64 * NW) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
-                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, int dim,
-                                                          int nl, int Gq, int xcd_map) {
-    const int j = blockIdx.y;
+// Database residues of the 45/46-bit limbs are stored as 48-bit integers (two per 12-byte load): -23 % HBM bytes on the
+// operand that dominates loop B.  Limb 0 (60 bit) and the rotated queries stay 8-byte.
+HD size_t db_limb_offset(const DbLayout &L, int N, int j) {
+    return L.packed ? (j == 0 ? 0 : (size_t)N * 8 + (size_t)(j - 1) * N * 6) : (size_t)j * N * 8;
+}
+template <bool PK, bool NT>
+DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
+    if (!PK) {
+        const ull2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(p)) : *reinterpret_cast<const ull2 *>(p);
+        ulonglong2 r;
+        r.x = v.x;
+        r.y = v.y;
+        return r;
+    }
+    const u3 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(p)) : *reinterpret_cast<const u3 *>(p);
+    ulonglong2 r;
+    r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
+    r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
+    return r;
+}
+
+// One Karatsuba step per coefficient: d0 += a0 b0, d2 += a1 b1, dk += (a0+a1)(b0+b1); d1 = dk - d0 - d2 at the end.
+// Three 64x64->128 products per coefficient instead of four — loop B is co-bound by the integer multiplier, not only
+// by HBM (gfx950 builds a 128-bit product from four v_mad_u64_u32).
+template <int BPP, int NW, bool NT, bool PK>
+__global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
+                                                             const unsigned char *__restrict__ db, u64 *__restrict__ acc,
+                                                             int dim, int nl, int Gq, int xcd_map, DbLayout L, int j0) {
+    const int j = blockIdx.y + j0;
     // consecutive workgroup ids are dealt round-robin over the 8 XCDs: give every XCD its own tiles and let the Gq block
     // groups of one tile follow each other ON THAT XCD, so they find the tile's rot lines in its L2
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -322,32 +348,32 @@ __global__ __launch_bounds__(64 * NW) void k_hydia_tensor(const ModC *__restrict
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ModC M = mod[j];
     const size_t c = (size_t)tile * 128 + lane * 2;
-    const size_t ps = (size_t)nl * N, cs = 2 * ps;  // poly stride, ciphertext stride
+    const size_t ps = (size_t)nl * N, cs = 2 * ps;  // rot / acc poly stride, ciphertext stride (elements)
     const int g0 = (gq * NW + wv) * BPP;
     const u64 *ra = rot + (size_t)j * N + c;
-    const u64 *da = db + (size_t)g0 * dim * cs + (size_t)j * N + c;
-    const size_t bs = (size_t)dim * cs;  // block stride
+    const unsigned char *da = db + (size_t)g0 * dim * L.ct_bytes + db_limb_offset(L, N, j) + c * (PK ? 6 : 8);
+    const size_t db_cs = L.ct_bytes, db_ps = L.poly_bytes, db_bs = (size_t)dim * L.ct_bytes;
     const int kbits = M.ks + 2;
-    const int chunk = (126 - 2 * kbits >= 30) ? dim : (1 << (126 - 2 * kbits));
-    u128 d0x[BPP], d0y[BPP], d1x[BPP], d1y[BPP], d2x[BPP], d2y[BPP];
+    const int chunk = (125 - 2 * kbits >= 30) ? dim : (1 << (125 - 2 * kbits));
+    u128 d0x[BPP], d0y[BPP], dkx[BPP], dky[BPP], d2x[BPP], d2y[BPP];
 #pragma unroll
-    for (int u = 0; u < BPP; u++) d0x[u] = d0y[u] = d1x[u] = d1y[u] = d2x[u] = d2y[u] = 0;
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    for (int u = 0; u < BPP; u++) d0x[u] = d0y[u] = dkx[u] = dky[u] = d2x[u] = d2y[u] = 0;
     for (int i0 = 0; i0 < dim; i0 += chunk) {
         const int i1 = i0 + chunk < dim ? i0 + chunk : dim;
         for (int i = i0; i < i1; i++) {
             const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
             const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs + ps);
+            const u64 sax = a0.x + a1.x, say = a0.y + a1.y;
 #pragma unroll
             for (int u = 0; u < BPP; u++) {
-                const ull2 b0 = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(da + u * bs + (size_t)i * cs));
-                const ull2 b1 = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(da + u * bs + (size_t)i * cs + ps));
+                const ulonglong2 b0 = db_load2<PK, NT>(da + u * db_bs + (size_t)i * db_cs);
+                const ulonglong2 b1 = db_load2<PK, NT>(da + u * db_bs + (size_t)i * db_cs + db_ps);
                 d0x[u] += (u128)a0.x * b0.x;
                 d0y[u] += (u128)a0.y * b0.y;
-                d1x[u] += (u128)a0.x * b1.x + (u128)a1.x * b0.x;
-                d1y[u] += (u128)a0.y * b1.y + (u128)a1.y * b0.y;
                 d2x[u] += (u128)a1.x * b1.x;
                 d2y[u] += (u128)a1.y * b1.y;
+                dkx[u] += (u128)sax * (b0.x + b1.x);
+                dky[u] += (u128)say * (b0.y + b1.y);
             }
             if (NW > 1) __builtin_amdgcn_s_barrier();  // keep the waves on the same diagonal (no memory wait implied)
         }
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) void k_hydia_tensor(const ModC *__restrict
 #pragma unroll
             for (int u = 0; u < BPP; u++) {
                 d0x[u] = reduce128(d0x[u], M); d0y[u] = reduce128(d0y[u], M);
-                d1x[u] = reduce128(d1x[u], M); d1y[u] = reduce128(d1y[u], M);
+                dkx[u] = reduce128(dkx[u], M); dky[u] = reduce128(dky[u], M);
                 d2x[u] = reduce128(d2x[u], M); d2y[u] = reduce128(d2y[u], M);
             }
         }
@@ -364,12 +390,39 @@ __global__ __launch_bounds__(64 * NW) void k_hydia_tensor(const ModC *__restrict
     for (int u = 0; u < BPP; u++) {
         ulonglong2 r0, r1, r2;
         r0.x = reduce128(d0x[u], M); r0.y = reduce128(d0y[u], M);
-        r1.x = reduce128(d1x[u], M); r1.y = reduce128(d1y[u], M);
         r2.x = reduce128(d2x[u], M); r2.y = reduce128(d2y[u], M);
+        r1.x = submod(submod(reduce128(dkx[u], M), r0.x, M.q), r2.x, M.q);
+        r1.y = submod(submod(reduce128(dky[u], M), r0.y, M.q), r2.y, M.q);
         u64 *o = acc + ((size_t)(g0 + u) * 3 * nl + j) * N + c;
         *reinterpret_cast<ulonglong2 *>(o) = r0;
         *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
         *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
+    }
+}
+
+// unpacked [X][2][nQ][N] u64  <->  database layout.  grid (N/512, nQ, X*2)
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_db_repack(int N, int nQ, u64 *__restrict__ plain, unsigned char *__restrict__ db,
+                                                   DbLayout L) {
+    const int j = blockIdx.y, xp = blockIdx.z, x = xp >> 1, p = xp & 1;
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    u64 *pl = plain + ((size_t)xp * nQ + j) * N + c;
+    const bool pk = L.packed && j > 0;
+    unsigned char *d = db + (size_t)x * L.ct_bytes + (size_t)p * L.poly_bytes + db_limb_offset(L, N, j) + c * (pk ? 6 : 8);
+    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
+    if (PACK) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pl);
+        if (pk) {
+            u3 w;
+            w.x = (unsigned)v.x;
+            w.y = (unsigned)(v.x >> 32) | ((unsigned)v.y << 16);
+            w.z = (unsigned)(v.y >> 16);
+            *reinterpret_cast<u3 *>(d) = w;
+        } else {
+            *reinterpret_cast<ulonglong2 *>(d) = v;
+        }
+    } else {
+        *reinterpret_cast<ulonglong2 *>(pl) = pk ? db_load2<true, false>(d) : db_load2<false, false>(d);
     }
 }
 
@@ -459,16 +512,28 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
     hipLaunchKernelGGL(k_rescale_combine, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, in, tmp, out, l, qlinv, in_ls);
 }
 template <int BPP, int NW>
-static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G, int dim,
-                          int nl) {
+static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G, int dim,
+                          int nl, const DbLayout &L) {
     const int Gq = G / (BPP * NW);
     static const int xcd_map = getenv("HYDIA_TENSOR_NOXCD") ? 0 : 1;
-    hipLaunchKernelGGL((k_hydia_tensor<BPP, NW>), dim3((N / 128) * Gq, nl), dim3(64 * NW), 0, st, mod, N, rot, db, acc, dim, nl,
-                       Gq, (N / 128) % 8 == 0 ? xcd_map : 0);
+    const int xm = (N / 128) % 8 == 0 ? xcd_map : 0;
+    const unsigned char *dbb = (const unsigned char *)db;
+    const dim3 blk(64 * NW);
+    if (L.packed) {  // limb 0 (8-byte residues) and limbs 1.. (6-byte residues) as two launches: no shared register budget
+        hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
+                           Gq, xm, L, 0);
+        if (nl > 1)
+            hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, true>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc,
+                               dim, nl, Gq, xm, L, 1);
+    } else {
+        hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, nl), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
+                           Gq, xm, L, 0);
+    }
 }
-// bpp = database blocks per wave, nw = waves per workgroup (0: largest that divides); both must divide G
-void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const u64 *db, u64 *acc, int G,
-                             int dim, int nl, int bpp, int nw) {
+// bpp = database blocks per wave, nw = max waves per workgroup (0: up to 16); both must divide G
+void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
+                             int dim, int nl, int bpp, int nw, int packed) {
+    DbLayout L = db_layout(N, nl, packed);
     int B = (bpp >= 4 && G % 4 == 0) ? 4 : (bpp >= 2 && G % 2 == 0) ? 2 : 1;
     const int rest = G / B;
     int W = 1;
@@ -478,11 +543,26 @@ void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *
             break;
         }
 #define HY_TENSOR_CASE(b, w) \
-    if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl);
+    if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl, L);
     HY_TENSOR_CASE(4, 16) HY_TENSOR_CASE(4, 8) HY_TENSOR_CASE(4, 4) HY_TENSOR_CASE(4, 2) HY_TENSOR_CASE(4, 1)
     HY_TENSOR_CASE(2, 16) HY_TENSOR_CASE(2, 8) HY_TENSOR_CASE(2, 4) HY_TENSOR_CASE(2, 2) HY_TENSOR_CASE(2, 1)
     HY_TENSOR_CASE(1, 16) HY_TENSOR_CASE(1, 8) HY_TENSOR_CASE(1, 4) HY_TENSOR_CASE(1, 2) HY_TENSOR_CASE(1, 1)
 #undef HY_TENSOR_CASE
+}
+DbLayout db_layout(int N, int nQ, int packed) {
+    DbLayout L;
+    L.packed = packed;
+    L.poly_bytes = packed ? (unsigned long long)N * 8 + (unsigned long long)(nQ - 1) * N * 6 : (unsigned long long)nQ * N * 8;
+    L.ct_bytes = 2 * L.poly_bytes;
+    return L;
+}
+void db_pack(hipStream_t st, int N, int nQ, const u64 *plain, void *db, int X, int packed) {
+    hipLaunchKernelGGL(k_db_repack<true>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, const_cast<u64 *>(plain),
+                       (unsigned char *)db, db_layout(N, nQ, packed));
+}
+void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, int X, int packed) {
+    hipLaunchKernelGGL(k_db_repack<false>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, plain, (unsigned char *)db,
+                       db_layout(N, nQ, packed));
 }
 const char *hydia_tensor_kernel_name() { return "k_hydia_tensor"; }
 void fill_uniform_hash(hipStream_t st, const ModC *mod, int N, u64 *dst, size_t n_limbpolys, int nl,
