@@ -243,6 +243,70 @@ DEV void p2_store(const NttStore &st, const ModC &M, u64 *d, int xp, int j, unsi
     }
 }
 
+// four consecutive coefficients idx..idx+3 of limb j of polynomial xp: operands prefetched BEFORE the last LDS exchange
+// (the loads overlap the barrier and the last two butterfly stages), results stored 16 bytes at a time unless the
+// automorphism scatters them
+struct P2Pre {
+    ulonglong2 in0, in1, ex0, ex1;  // `in` operand; addend (mode 1) or subtrahend (mode 2)
+    bool has_ex;
+};
+template <int ST>
+DEV P2Pre p2_prefetch(const NttStore &st, int xp, int j, unsigned idx) {
+    constexpr size_t N = 32768;
+    P2Pre r;
+    r.has_ex = false;
+    r.ex0 = r.ex1 = make_ulonglong2(0, 0);
+    const u64 *pi = st.in + ((size_t)xp * st.in_ls + j) * N + idx;
+    r.in0 = *reinterpret_cast<const ulonglong2 *>(pi);
+    r.in1 = *reinterpret_cast<const ulonglong2 *>(pi + 2);
+    if (ST == 1) {
+        const int x = xp >> 1, p = xp & 1;
+        if (st.addend && p < st.add_polys) {
+            const u64 *pa = st.addend + (size_t)x * st.add_x + (size_t)p * st.add_p + (size_t)j * N + idx;
+            r.ex0 = *reinterpret_cast<const ulonglong2 *>(pa);
+            r.ex1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
+            r.has_ex = true;
+        }
+    } else if (ST == 2) {
+        if (st.sub) {
+            const u64 *ps = st.sub + ((size_t)xp * st.sub_ls + j) * N + idx;
+            r.ex0 = *reinterpret_cast<const ulonglong2 *>(ps);
+            r.ex1 = *reinterpret_cast<const ulonglong2 *>(ps + 2);
+            r.has_ex = true;
+        }
+    }
+    return r;
+}
+template <int ST>
+DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned idx, const u64 v[4], const P2Pre &pre) {
+    constexpr size_t N = 32768;
+    const u64 q = M.q, mul = st.mul.s[j], muls = st.mul.s_sh[j];
+    const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
+    const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
+    u64 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        r[k] = mulmod_shoup(submod(iv[k], v[k], q), mul, muls, q);
+        if (ST == 1) {
+            if (pre.has_ex) r[k] = addmod(r[k], ev[k], q);
+            if (st.dbl) r[k] = addmod(r[k], r[k], q);
+        } else {
+            if (pre.has_ex) r[k] = submod(r[k], ev[k], q);
+            if (st.has_addc && (xp % st.npoly) == 0) r[k] = addmod(r[k], st.addc[j], q);
+        }
+    }
+    u64 *o = st.out + ((size_t)xp * st.nl + j) * N;
+    unsigned g = 1u;
+    if (ST == 1 && st.ginv) g = st.ginv[st.same_g ? 0 : (xp >> 1)];
+    if (g != 1u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[perm_idx(idx + k, g)] = r[k];
+    } else {
+        *reinterpret_cast<ulonglong2 *>(o + idx) = make_ulonglong2(r[0], r[1]);
+        *reinterpret_cast<ulonglong2 *>(o + idx + 2) = make_ulonglong2(r[2], r[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ pass 2 (contiguous)
 // 256 threads: blk = t>>5, w = t&31.  NP polynomials (1 or 2, same modulus) share every twiddle load.  LDS rows of 32
 // coefficients are padded to 36 so phase B's (a, b) reads hit 64 distinct banks.
@@ -307,6 +371,13 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 for (int k = 0; k < 8; k++) lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
             }
         }
+        P2Pre pre[2][NP];
+        if (ST != 0) {
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh));
+        }
         __syncthreads();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
 #pragma unroll
@@ -329,11 +400,8 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     *reinterpret_cast<ulonglong2 *>(d[p] + e) = o0;
                     *reinterpret_cast<ulonglong2 *>(d[p] + e + 2) = o1;
                 } else {
-                    const unsigned idx = (unsigned)(B0 + e);
-                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx, ar.fin_fwd(c0));
-                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx + 1, ar.fin_fwd(c1));
-                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx + 2, ar.fin_fwd(c2));
-                    p2_store<ST>(stp, M, nullptr, xp0 + p, slot, idx + 3, ar.fin_fwd(c3));
+                    const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
+                    p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[hh][p]);
                 }
             }
         }
