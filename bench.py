@@ -81,14 +81,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = torch = None
+    # HYDIA_BENCH_REHEARSE=1: every rank computes on GPU 0 and the gather goes through gloo/host memory — lets the multi-rank
+    # control flow be exercised on a one-GPU box (never used for reported numbers)
+    rehearse = os.environ.get("HYDIA_BENCH_REHEARSE") == "1"
     if world > 1:
         import torch  # noqa: F811  (device memory + RCCL only)
         import torch.distributed as dist  # noqa: F811
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import image_matching_amd as im
-    cc = im.Context(im.default_params(), local_rank)
+    cc = im.Context(im.default_params(), 0 if rehearse else local_rank)
     n = 1 << args.log2n
     dim, S = cc.dim, cc.slots
     G = -(-n // S)
@@ -115,19 +121,25 @@ def main():
         if world > 1:
             nonlocal gather_buf, gather_list
             cnt, npoly, nl, _ = res.shape()
-            if gather_buf is None:
-                gather_buf = torch.empty(cnt * npoly * nl * cc.N, dtype=torch.int64, device="cuda")
+            if rehearse:
+                gather_buf = torch.from_numpy(res.export().view(np.int64).reshape(-1))
                 gather_list = [torch.empty_like(gather_buf) for _ in range(world)] if rank == 0 else None
-            res.copy_to_device(gather_buf.data_ptr())
+            else:
+                if gather_buf is None:
+                    gather_buf = torch.empty(cnt * npoly * nl * cc.N, dtype=torch.int64, device="cuda")
+                    gather_list = [torch.empty_like(gather_buf) for _ in range(world)] if rank == 0 else None
+                res.copy_to_device(gather_buf.data_ptr())
             dist.gather(gather_buf, gather_list, dst=0)
         return res
 
     def fence():
         cc.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if not rehearse:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if not rehearse:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -139,11 +151,19 @@ def main():
     fence()
     elapsed = time.time() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ms_tensor, launches = cc.kernel_time("hydia_tensor")
+    # secondary figure of SURVEY 8d (outside the timed region): computeSimilarity alone = loop A + loop B + relin + rescale
+    cc.sync()
+    t1 = time.time()
+    for _ in range(3):
+        sim = sender.computeSimilarity(qc)
+    cc.sync()
+    ms_similarity = (time.time() - t1) / 3 * 1e3
+    del sim
     # correctness of what was just timed: decrypt this rank's index result (rank 0 also decrypts the gathered ones)
     correct = True
     if not args.random_db:
@@ -151,7 +171,10 @@ def main():
         if world > 1 and rank == 0:
             cnt, npoly, nl, scale = res.shape()
             for r in range(1, world):
-                other = cc.ct_from_device(gather_list[r].data_ptr(), cnt, npoly, nl, scale)
+                if rehearse:
+                    other = cc.import_ct(gather_list[r].numpy().view(np.uint64).reshape(cnt, npoly, nl, cc.N), scale)
+                else:
+                    other = cc.ct_from_device(gather_list[r].data_ptr(), cnt, npoly, nl, scale)
                 correct = correct and receiver.decryptIndex(other) == planted
 
     if rank == 0:
@@ -183,7 +206,9 @@ def main():
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3", "sharding": "row-block per GPU, RCCL gather of results",
                        "db_storage": "%.1f GiB resident (45/46-bit limbs held as 48-bit residues)" % (cc.db_stats()[2] / 2 ** 30),
                        "result_check": "decrypted index == planted matches" if not args.random_db else "skipped (random DB)",
-                       "result_correct": bool(correct), "setup_s": {"keygen": round(t_keygen, 2), "enroll": round(t_enroll, 2)}},
+                       "result_correct": bool(correct), "setup_s": {"keygen": round(t_keygen, 2), "enroll": round(t_enroll, 2)},
+                       "secondary": {"computeSimilarity_ms_per_query_rank0": round(ms_similarity, 3),
+                                     "computeSimilarity_vectors_per_s_per_gpu": round(n / ms_similarity * 1e3)}},
             "roofline": {"kernel": "k_hydia_tensor", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3,
