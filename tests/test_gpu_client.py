@@ -120,3 +120,53 @@ def test_reference_datasets_end_to_end_full_ring(im):
         assert receiver.decryptMembership(sender.membershipScenario(qc)) is True
         assert receiver.decryptIndex(sender.indexScenario(qc)) == [0]
     cc.close()
+
+
+@pytest.mark.parametrize("n", [40000, 70000])
+def test_multi_block_full_ring_end_to_end(im, n):
+    """G = 3 and G = 5 blocks at N = 2^15 (odd block counts exercise the loop-B launch fallbacks and the batched comparator):
+    decrypted scores vs plaintext cosine (1e-4, src/main_accuracy.cpp:359-360), index = planted matches, membership true."""
+    cc = im.Context()
+    cc.keygen(11)
+    rng = np.random.default_rng(n)
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
+    planted = sorted([3, 16384 + 77, n - 1])
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    query = np.ones(512)
+    cos = (db / np.linalg.norm(db, axis=1, keepdims=True)) @ (query / np.linalg.norm(query))
+    im.DiagonalEnroller(cc, n).serializeDB(db, seed=3)
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    qc = receiver.encryptQuery(query, seed=5, nonce=1)
+    sim = sender.computeSimilarity(qc)
+    assert len(sim) == -(-n // 16384)
+    scores = cc.decrypt(sim).reshape(-1)
+    assert np.abs(scores[:n] - cos).max() < TOL and np.abs(scores[n:]).max() < TOL
+    assert receiver.decryptIndex(sender.indexScenario(qc)) == planted
+    assert receiver.decryptMembership(sender.membershipScenario(qc)) is True
+    cc.close()
+
+
+def test_cli_image_matching_on_reference_dataset(tmp_path):
+    """./ImageMatching ../test/2_10.dat 5 (BASELINE config 1) through the C++ role classes: stdout and latency.csv row."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "image_matching_amd", "ImageMatching")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    g = np.load(os.path.join(GOLDEN, "dataset_2_10.npz"))
+    dat = tmp_path / "2_10.dat"
+    with open(dat, "w") as f:
+        f.write("%d\n" % int(g["n"]))
+        f.write(" ".join(str(int(v)) for v in g["query"]) + " \n")
+        for row in g["db"]:
+            f.write(" ".join(str(int(v)) for v in row) + " \n")
+    (tmp_path / "latency.csv").write_text("")
+    out = subprocess.run([exe, str(dat), "5"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Membership scenario: true" in out.stdout and "Index scenario: [ 0 ]" in out.stdout
+    row = (tmp_path / "latency.csv").read_text().strip().split(",")
+    assert row[0] == "Diagonal" and row[1] == "1024" and row[10] == "true" and row[11] == "[ 0 ]"
+    # approaches 1-4 are not part of this framework: explicit refusal, no silent fallback
+    out = subprocess.run([exe, str(dat), "4"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "only approach 5" in out.stderr

@@ -195,3 +195,19 @@ def test_reference_dataset_2_10_full_ring(im):
     gm.data()[:] = gmem.export()[0]
     assert Or.decrypt_membership(gm) is True
     cc.close()
+
+
+def test_ntt15_pair_path_and_mixed_limbs(im):
+    """Even polynomial counts take the two-polynomials-per-workgroup pass; both arithmetic back ends (60-bit integer,
+    45-bit FP64) must agree with the oracle bit for bit, forward and inverse."""
+    P = O.Params()
+    cc = make_ctx(im, P)
+    rng = np.random.default_rng(15)
+    for m in (0, 5, 11, 13):
+        q = int(P.moduli[m])
+        a = rng.integers(0, q, size=(4, P.N), dtype=np.uint64)
+        a[3] = q - 1
+        f = cc.ntt(a, m)
+        assert np.array_equal(f, np.stack([P.ntt_fwd(r, m) for r in a])), m
+        assert np.array_equal(cc.ntt(f, m, inverse=True), a), m
+    cc.close()
