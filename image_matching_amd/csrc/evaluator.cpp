@@ -233,6 +233,76 @@ void Context::rescale(Ct &c, const Ct *sub, const double *addc) {
     pool.put(t);
     c = std::move(out);
 }
+void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc) {
+    if (c.npoly != 3) throw std::runtime_error("hydia: relin_rescale needs a 3-component ciphertext");
+    const int nl = c.nl, l = nl - 1;
+    if (prm.logN != 15 || !merge_rescale || l < 1 || l > HY_LC_LIMBS) {  // generic rings: the two steps in sequence
+        relinearize(c, dbl);
+        rescale(c, sub, addc);
+        return;
+    }
+    if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
+    if (sub && (sub->X != c.X || sub->npoly != 2 || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
+    const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
+    u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
+    modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
+    const LimbSel esel = sel_ext(nl);
+    u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
+    timer_begin("ks_inner_product");
+    hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel);
+    timer_end("ks_inner_product");
+    pool.put(dig);
+    // P limbs -> coefficient form (pre-multiplied by (P/p_k)^{-1})
+    const LimbSel psel = sel_range(nQ, nT);
+    u64 *y = pool.get((size_t)XP * nP * N * sizeof(u64));
+    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, XP, psel, scale_of(psel, Phat_inv, true));
+    // limb l of the would-be ModDown output (+ d_l, doubled), to the coefficient domain
+    const LimbSel qsel_full = sel_q(nl);
+    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
+    const ScaleSel pinv_sel = scale_of(qsel_full, pinv, false);
+    u64 *u = pool.get((size_t)XP * N * sizeof(u64));
+    hk::moddown_last_limb(stream, d_mod, N, acc, nE, c.d, c.ct_elems(), c.poly_elems(), u, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
+                          dbl ? 1 : 0);
+    const LimbSel last = sel_range(l, l + 1);
+    ntt_inv(u, u, (size_t)N, (size_t)N, XP, last, scale_ninv(last));
+    // coefficient-domain correction of every remaining limb, then ONE forward NTT per limb with the merged epilogue
+    ConvTab tab{};
+    tab.ns = nP;
+    tab.nt = nl;
+    for (int k = 0; k < nP; k++)
+        for (int j = 0; j < nl; j++) tab.f[k][j] = Phat_mod_q[k][j];
+    u64 *w = pool.get((size_t)XP * l * N * sizeof(u64));
+    hk::moddown_rescale_conv(stream, d_mod, N, y, u, w, XP, l, nP, tab, pinv_sel, dbl ? 1 : 0);
+    const LimbSel qsel = sel_q(l);
+    Ct out(this, X, 2, l, c.scale / (double)q[l]);
+    std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
+    NttLoad ld{};
+    NttStore stp{};
+    stp.mode = 3;
+    stp.out = out.d;
+    stp.nl = l;
+    stp.in = acc;
+    stp.in_ls = nE;
+    stp.mul = pinv_sel;
+    stp.mul2 = scale_of(qsel, qi, false);
+    stp.addend = c.d;
+    stp.add_x = c.ct_elems();
+    stp.add_p = c.poly_elems();
+    stp.add_polys = 2;
+    stp.dbl = dbl ? 1 : 0;
+    stp.sub = sub ? sub->d : nullptr;
+    stp.sub_ls = sub ? sub->lstride : 0;
+    stp.has_addc = addc ? 1 : 0;
+    stp.npoly = 2;
+    if (addc)
+        for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out.scale, q[j]);
+    hk::ntt15_forward_fused(stream, tabs, w, w, (size_t)l * N, (size_t)l * N, XP, qsel, ld, stp);
+    pool.put(w);
+    pool.put(u);
+    pool.put(y);
+    pool.put(acc);
+    c = std::move(out);
+}
 Ct Context::clone(const Ct &a) {
     Ct o(this, a.X, a.npoly, a.nl, a.scale);
     hk::copy_limbs(stream, N, a.d, o.d, a.poly_elems(), o.poly_elems(), a.X * a.npoly, a.nl);
@@ -303,8 +373,7 @@ Ct Context::mult(const Ct &a, const Ct &b) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
     Ct o = mult_norelin(x, y);
-    relinearize(o);
-    rescale(o);
+    relin_rescale(o);
     return o;
 }
 // EvalRotate on every ciphertext of the batch (EvalSum's step, sender_diag.cpp:47)
@@ -349,8 +418,7 @@ Ct Context::similarity(const Ct &qc) {
     timer_begin("hydia_tensor");
     hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
     timer_end("hydia_tensor");
-    relinearize(acc);
-    rescale(acc);
+    relin_rescale(acc);
     return acc;
 }
 
@@ -367,10 +435,9 @@ Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
     Ct o = cx->mult_norelin(x, y);
-    cx->relinearize(o, true);
     const double minus_one = -1.0;
-    if (c) cx->rescale(o, c, nullptr);
-    else cx->rescale(o, nullptr, &minus_one);
+    if (c) cx->relin_rescale(o, true, c, nullptr);
+    else cx->relin_rescale(o, true, nullptr, &minus_one);
     return o;
 }
 Ct cheb_leaf(Cheb &ch, const double *c, int deg) {

@@ -152,6 +152,11 @@ struct Context : HostParams {
     void relinearize(Ct &c, bool dbl = false);  // [X][3][nl] -> [X][2][nl]; dbl: result doubled (2ab of a Chebyshev step)
     // drop the last limb; optionally fused: result -= sub (a view at the new level), result += addc (constant, poly 0)
     void rescale(Ct &c, const Ct *sub = nullptr, const double *addc = nullptr);
+    // RelinearizeInPlace followed by RescaleInPlace (sender_diag.cpp:79-80) as ONE pipeline with bit-identical results:
+    // the dropped limb of the ModDown output is obtained in the coefficient domain, so ModDown's and Rescale's
+    // corrections share a single forward NTT per remaining limb ((l+1) transforms per polynomial saved)
+    void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr);
+    bool merge_rescale = true;      // HYDIA_NO_MERGE_RESCALE: run the two steps separately (A/B)
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
     int tensor_bpp = 2;             // DB blocks per wave in loop B (HYDIA_TENSOR_BPP; 4 spills past 168 VGPRs)

@@ -55,12 +55,13 @@ struct NttLoad {
 };
 // Fused epilogue of its second pass: what is done with the evaluation-form value v of limb j
 struct NttStore {
-    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine
+    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale
     u64 *out;             // modes 1,2: destination, compact [xp][nl][N]
     int nl;               // limbs of `out`
     const u64 *in;        // mode 1: acc [xp][in_ls][N] (Q limbs first); mode 2: ciphertext being rescaled [xp][in_ls][N]
     int in_ls;
     ScaleSel mul;         // mode 1: P^{-1} mod q_j; mode 2: q_l^{-1} mod q_j   -> out = (in - v) * mul
+    ScaleSel mul2;        // mode 3: q_l^{-1} mod q_j:  out = ((in * mul + addend)(x2) - v) * mul2 (- sub)(+ addc)
     const u64 *addend;    // mode 1: + addend[x*add_x + p*add_p + j*N + c] for p < add_polys (xp = 2x + p)
     size_t add_x, add_p;
     int add_polys;
@@ -133,6 +134,15 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
                      const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys, u64 *out, int X, int nl,
                      const ScaleSel &pinv, const unsigned *galois /* device [X] (or [1] with same_g) or null */,
                      int same_g);
+// merged ModDown + Rescale (bit-identical to doing them in sequence), coefficient-domain part.
+// u  [xp][N]      : INTT of (acc_l P^{-1} + d_l)(x2), the dropped limb q_l of the would-be ModDown output
+// y  [xp][nP][N]  : INTT of acc's P limbs times (P/p_k)^{-1}
+// w  [xp][l][N]   : (conv_j P^{-1})(x2) + centred(y_l) mod q_j, whose NTT is subtracted in the pass-2 epilogue (mode 3)
+void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
+                          const ConvTab &tab, const ScaleSel &pinv, int dbl);
+// u[xp][c] = (acc[xp][l][c] * pinv_l + addend[x*add_x + p*add_p + l*N + c])(x2)   (evaluation form, limb l)
+void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
+                       size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl);
 // rescale: t = last limb in coefficient form [X][N]; tmp[x][j][c] = centred t mod q_j (coefficient form)
 void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l);
 // out[x][j][c] = (in[x][j][c] - tmp[x][j][c]) * qlinv[j]; in has nl=l+1 limbs per x, out has l

@@ -279,6 +279,76 @@ __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict_
     if (addend && p < add_polys) v = addmod(v, addend[(size_t)x * axs + (size_t)p * aps + (size_t)j * N + c], q);
     out[((size_t)xp * nl + j) * N + co] = v;
 }
+// grid (N/512, XP): see moddown_rescale_conv in kernels.h.  Two coefficients per thread.
+__global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
+                                                              const u64 *__restrict__ u, u64 *__restrict__ w, int l, int nP,
+                                                              ConvTab tab, ScaleSel pinv, int dbl) {
+    const int xp = blockIdx.y;
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    ulonglong2 v[HY_MAX_DIGIT];
+#pragma unroll
+    for (int s = 0; s < HY_MAX_DIGIT; s++)
+        if (s < nP) v[s] = *reinterpret_cast<const ulonglong2 *>(y + ((size_t)xp * nP + s) * N + c);
+    // the dropped limb of the ModDown output, coefficient form: y_l = u - conv_l P^{-1} (doubled when dbl)
+    const ModC Ml = mod[l];
+    u128 ax = 0, ay = 0;
+#pragma unroll
+    for (int s = 0; s < HY_MAX_DIGIT; s++)
+        if (s < nP) {
+            ax += (u128)v[s].x * tab.f[s][l];
+            ay += (u128)v[s].y * tab.f[s][l];
+        }
+    u64 mx = mulmod_shoup(reduce128(ax, Ml), pinv.s[l], pinv.s_sh[l], Ml.q);
+    u64 my = mulmod_shoup(reduce128(ay, Ml), pinv.s[l], pinv.s_sh[l], Ml.q);
+    if (dbl) {
+        mx = addmod(mx, mx, Ml.q);
+        my = addmod(my, my, Ml.q);
+    }
+    const ulonglong2 uu = *reinterpret_cast<const ulonglong2 *>(u + (size_t)xp * N + c);
+    const u64 ylx = submod(uu.x, mx, Ml.q), yly = submod(uu.y, my, Ml.q);
+    const u64 half = Ml.q >> 1;
+    for (int j = 0; j < l; j++) {
+        const ModC M = mod[j];
+        u128 bx = 0, by = 0;
+#pragma unroll
+        for (int s = 0; s < HY_MAX_DIGIT; s++)
+            if (s < nP) {
+                bx += (u128)v[s].x * tab.f[s][j];
+                by += (u128)v[s].y * tab.f[s][j];
+            }
+        u64 wx = mulmod_shoup(reduce128(bx, M), pinv.s[j], pinv.s_sh[j], M.q);
+        u64 wy = mulmod_shoup(reduce128(by, M), pinv.s[j], pinv.s_sh[j], M.q);
+        if (dbl) {
+            wx = addmod(wx, wx, M.q);
+            wy = addmod(wy, wy, M.q);
+        }
+        const u64 rx = ylx > half ? negmod(reduce64(Ml.q - ylx, M), M.q) : reduce64(ylx, M);
+        const u64 ry = yly > half ? negmod(reduce64(Ml.q - yly, M), M.q) : reduce64(yly, M);
+        ulonglong2 o;
+        o.x = addmod(wx, rx, M.q);
+        o.y = addmod(wy, ry, M.q);
+        *reinterpret_cast<ulonglong2 *>(w + ((size_t)xp * l + j) * N + c) = o;
+    }
+}
+// grid (N/512, XP)
+__global__ __launch_bounds__(256) void k_moddown_last_limb(const ModC *__restrict__ mod, int N, const u64 *__restrict__ acc,
+                                                           int acc_limbs, const u64 *__restrict__ addend, size_t add_x,
+                                                           size_t add_p, u64 *__restrict__ u, int l, u64 pinv, u64 pinv_sh,
+                                                           int dbl) {
+    const int xp = blockIdx.y, x = xp >> 1, p = xp & 1;
+    const u64 q = mod[l].q;
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(acc + ((size_t)xp * acc_limbs + l) * N + c);
+    const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(addend + (size_t)x * add_x + (size_t)p * add_p + (size_t)l * N + c);
+    ulonglong2 r;
+    r.x = addmod(mulmod_shoup(a.x, pinv, pinv_sh, q), d.x, q);
+    r.y = addmod(mulmod_shoup(a.y, pinv, pinv_sh, q), d.y, q);
+    if (dbl) {
+        r.x = addmod(r.x, r.x, q);
+        r.y = addmod(r.y, r.y, q);
+    }
+    *reinterpret_cast<ulonglong2 *>(u + (size_t)xp * N + c) = r;
+}
 // grid (N/256, l, X)
 __global__ __launch_bounds__(256) void k_rescale_spread(const ModC *__restrict__ mod, int N, const u64 *__restrict__ t,
                                                         u64 *__restrict__ tmp, int l) {
@@ -503,6 +573,15 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
                      const ScaleSel &pinv, const unsigned *galois, int same_g) {
     hipLaunchKernelGGL(k_moddown_combine, dim3((1 << logN) / 256, nl, X * 2), dim3(256), 0, st, mod, logN, acc, acc_limbs,
                        conv, addend, axs, aps, add_polys, out, nl, pinv, galois, same_g);
+}
+void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
+                          const ConvTab &tab, const ScaleSel &pinv, int dbl) {
+    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab, pinv, dbl);
+}
+void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
+                       size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl) {
+    hipLaunchKernelGGL(k_moddown_last_limb, dim3(N / 512, XP), dim3(256), 0, st, mod, N, acc, acc_limbs, addend, add_x, add_p, u, l,
+                       pinv, pinv_sh, dbl);
 }
 void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l) {
     hipLaunchKernelGGL(k_rescale_spread, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, t, tmp, l);

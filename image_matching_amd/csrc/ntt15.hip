@@ -19,6 +19,8 @@
 // 16-byte pair loads shared by the TWO polynomials a workgroup transforms together.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct IntA {
@@ -247,8 +249,9 @@ DEV void p2_store(const NttStore &st, const ModC &M, u64 *d, int xp, int j, unsi
 // (the loads overlap the barrier and the last two butterfly stages), results stored 16 bytes at a time unless the
 // automorphism scatters them
 struct P2Pre {
-    ulonglong2 in0, in1, ex0, ex1;  // `in` operand; addend (mode 1) or subtrahend (mode 2)
-    bool has_ex;
+    ulonglong2 in0, in1, ex0, ex1;  // `in` operand; addend (modes 1, 3) or subtrahend (mode 2)
+    ulonglong2 sb0, sb1;            // subtrahend of mode 3
+    bool has_ex, has_sb;
 };
 template <int ST>
 DEV P2Pre p2_prefetch(const NttStore &st, int xp, int j, unsigned idx) {
@@ -259,13 +262,21 @@ DEV P2Pre p2_prefetch(const NttStore &st, int xp, int j, unsigned idx) {
     const u64 *pi = st.in + ((size_t)xp * st.in_ls + j) * N + idx;
     r.in0 = *reinterpret_cast<const ulonglong2 *>(pi);
     r.in1 = *reinterpret_cast<const ulonglong2 *>(pi + 2);
-    if (ST == 1) {
+    r.sb0 = r.sb1 = make_ulonglong2(0, 0);
+    r.has_sb = false;
+    if (ST == 1 || ST == 3) {
         const int x = xp >> 1, p = xp & 1;
         if (st.addend && p < st.add_polys) {
             const u64 *pa = st.addend + (size_t)x * st.add_x + (size_t)p * st.add_p + (size_t)j * N + idx;
             r.ex0 = *reinterpret_cast<const ulonglong2 *>(pa);
             r.ex1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
             r.has_ex = true;
+        }
+        if (ST == 3 && st.sub) {
+            const u64 *ps = st.sub + ((size_t)xp * st.sub_ls + j) * N + idx;
+            r.sb0 = *reinterpret_cast<const ulonglong2 *>(ps);
+            r.sb1 = *reinterpret_cast<const ulonglong2 *>(ps + 2);
+            r.has_sb = true;
         }
     } else if (ST == 2) {
         if (st.sub) {
@@ -284,6 +295,24 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
     const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
     u64 r[4];
+    if (ST == 3) {  // ((in P^{-1} + addend)(x2) - v) q_l^{-1} (- sub)(+ addc): ModDown and Rescale in one epilogue
+        const u64 m2 = st.mul2.s[j], m2s = st.mul2.s_sh[j];
+        const u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u64 t = mulmod_shoup(iv[k], mul, muls, q);
+            if (pre.has_ex) t = addmod(t, ev[k], q);
+            if (st.dbl) t = addmod(t, t, q);
+            t = mulmod_shoup(submod(t, v[k], q), m2, m2s, q);
+            if (pre.has_sb) t = submod(t, sv[k], q);
+            if (st.has_addc && (xp % st.npoly) == 0) t = addmod(t, st.addc[j], q);
+            r[k] = t;
+        }
+        u64 *o3 = st.out + ((size_t)xp * st.nl + j) * N;
+        *reinterpret_cast<ulonglong2 *>(o3 + idx) = make_ulonglong2(r[0], r[1]);
+        *reinterpret_cast<ulonglong2 *>(o3 + idx + 2) = make_ulonglong2(r[2], r[3]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         r[k] = mulmod_shoup(submod(iv[k], v[k], q), mul, muls, q);
@@ -517,10 +546,14 @@ static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u6
     ScaleSel dummy = {};
     hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, dummy, ld);
 }
+static bool pair_polys() {  // HYDIA_NTT_NP1: one polynomial per workgroup (half the LDS, twice the twiddle loads)
+    static const bool v = getenv("HYDIA_NTT_NP1") == nullptr;
+    return v;
+}
 template <int ST>
 static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel,
                           const NttStore &stp) {
-    if (X % 2 == 0)
+    if (X % 2 == 0 && pair_polys())
         hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, stp);
@@ -541,13 +574,14 @@ void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64
     else launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
     if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, stp);
     else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, stp);
+    else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, stp);
     else launch_p2_fwd<0>(st, T, dst, dso, X, sel, stp);
 }
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                    const LimbSel &sel, const ScaleSel &scale) {
     NttLoad ld{};
     NttStore stp{};
-    if (X % 2 == 0)
+    if (X % 2 == 0 && pair_polys())
         hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, stp);
