@@ -5,6 +5,7 @@ the thin Python host mirror of the reference's role classes over that C-ABI; it 
 raises if the HIP library is missing.
 """
 from .hydia import (Context, Ciphertext, DiagonalEnroller, DiagonalReceiver, DiagonalSender, HydiaError,  # noqa: F401
+                    HersEnroller, HersReceiver, HersSender,
                     default_params, describe_params, compute_required_depth, lib_path, load_library)
 
 MATCH_THRESHOLD = 0.44  # include/config.h:9

@@ -353,6 +353,7 @@ int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors) {
     API_BEGIN
     REQUIRE(ctx && n_vectors >= 1, "bad argument");
     db_alloc(ctx->cx, n_vectors, hydia_db_num_cts(ctx, n_vectors));
+    ctx->cx.db_kind = 5;
     return HYDIA_OK;
     API_END
 }
@@ -369,6 +370,7 @@ int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data) {
     cx.db_store(t, tmp, 1);
     cx.sync();
     cx.pool.put(tmp);
+    if (cx.db_kind == 0) cx.db_kind = 5;
     return HYDIA_OK;
     API_END
 }
@@ -402,6 +404,7 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     }
     cx.sync();
     cx.pool.put(tmp);
+    cx.db_kind = 5;
     return HYDIA_OK;
     API_END
 }
@@ -411,6 +414,25 @@ int hydia_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]
     Context &cx = ctx->cx;
     db_alloc(cx, n, hydia_db_num_cts(ctx, n));
     client_enroll(cx, db, n, seed);
+    cx.db_kind = 5;
+    return HYDIA_OK;
+    API_END
+}
+int hydia_hers_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
+    API_BEGIN
+    REQUIRE(ctx && db && seed && n >= 1, "bad argument");
+    Context &cx = ctx->cx;
+    const size_t G = (n + cx.slots - 1) / cx.slots;  // enroller_hers.cpp:59-60
+    db_alloc(cx, n, G * cx.prm.dim);
+    client_hers_enroll(cx, db, n, seed);
+    cx.db_kind = 4;
+    return HYDIA_OK;
+    API_END
+}
+int hydia_hers_encrypt_query(hydia_ctx *ctx, const double *query, const uint8_t seed[32], uint64_t nonce0, hydia_ct **out) {
+    API_BEGIN
+    REQUIRE(ctx && query && seed && out, "null argument");
+    *out = wrap(client_hers_encrypt_query(ctx->cx, query, seed, nonce0));
     return HYDIA_OK;
     API_END
 }
@@ -437,6 +459,9 @@ int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *query, double delta,
     SENDER_CALL(ctx->cx.chebyshev_compare(query->c, delta, (int)sign_depth))
 }
 int hydia_sum_and_evalsum(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.sum_and_evalsum(query->c)) }
+int hydia_hers_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.hers_similarity(query->c)) }
+int hydia_hers_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.hers_index_scenario(query->c)) }
+int hydia_hers_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.hers_membership_scenario(query->c)) }
 
 // ------------------------------------------------------------------ primitives
 int hydia_ntt(hydia_ctx *ctx, uint64_t *data, uint32_t count, uint32_t m, int inverse) {

@@ -1,7 +1,7 @@
 // image_matching_amd/csrc/cli_main.cpp — `ImageMatching <file.dat> 5`: the reference's latency driver for approach 5
 // (/root/reference/src/main.cpp:40-110 argument handling, :216-247 dataset + enrolment, :330-393 the five timed phases,
 // latency.csv row with the columns of /root/reference/tools/setup_experiment.sh:4-16) on the MI355X stack.
-// Approaches 1-4 are the paper's comparison baselines and are not part of this framework.
+// Approach 4 (HERS) runs on the same kernels; approaches 1-3 are not part of this framework.
 #include <chrono>
 #include <fstream>
 #include <iostream>
@@ -46,8 +46,8 @@ int main(int argc, char *argv[]) {
         cerr << "Error: approach must be from 1 to 5" << endl;
         return 1;
     }
-    if (expApproach != 5) {
-        cerr << "Error: only approach 5 (novel diagonal transform, HyDia) is built in hydia-mi355x" << endl;
+    if (expApproach != 5 && expApproach != 4) {
+        cerr << "Error: only approach 5 (novel diagonal transform, HyDia) and approach 4 (HERS) are built in hydia-mi355x" << endl;
         return 1;
     }
     ofstream expStream;
@@ -57,8 +57,13 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     size_t multDepth = OpenFHEWrapper::computeRequiredDepth(expApproach);
-    cout << "Experimental approach: Novel diagonal transform" << endl;
-    expStream << "Diagonal," << flush;
+    if (expApproach == 5) {
+        cout << "Experimental approach: Novel diagonal transform" << endl;
+        expStream << "Diagonal," << flush;
+    } else {
+        cout << "Experimental approach: HERS paper" << endl;
+        expStream << "HERS," << flush;
+    }
 
     CryptoContext cc = GenCryptoContext(multDepth, 45, VECTOR_DIM);
     if (!cc->h) return 2;
@@ -78,16 +83,19 @@ int main(int argc, char *argv[]) {
         for (size_t j = 0; j < VECTOR_DIM; j++) fileStream >> plaintextVectors[i][j];
     fileStream.close();
     cout << "Encrypting database vectors... " << endl;
-    {
+    if (expApproach == 5) {
         DiagonalEnroller enroller(cc, numVectors);
+        enroller.serializeDB(plaintextVectors);
+    } else {
+        HersEnroller enroller(cc, numVectors);
         enroller.serializeDB(plaintextVectors);
     }
 
     cout << endl << "\tRunning Experiments:" << endl;
     chrono::steady_clock::time_point start, end;
     chrono::duration<double> duration;
-    Receiver *receiver = new DiagonalReceiver(cc, numVectors);
-    Sender *sender = new DiagonalSender(cc, numVectors);
+    Receiver *receiver = expApproach == 5 ? (Receiver *)new DiagonalReceiver(cc, numVectors) : (Receiver *)new HersQueryReceiver(cc, numVectors);
+    Sender *sender = expApproach == 5 ? (Sender *)new DiagonalSender(cc, numVectors) : (Sender *)new HersSender(cc, numVectors);
 
     cout << "[Receiver]\tEncrypting query vector... " << flush;
     start = chrono::steady_clock::now();

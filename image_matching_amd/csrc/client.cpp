@@ -9,6 +9,7 @@
 // (VectorUtils::plaintextNormalize, /root/reference/src/vector_utils.cpp:32-51) and schedules launches.
 #include "client.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -211,6 +212,48 @@ void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]) {
     cx.pool.put(d_cts);
     cx.pool.put((u64 *)d_slots);
     cx.pool.put((u64 *)d_rows);
+}
+
+#define HY_HERS_NONCE_BASE (1ull << 37)
+// HersEnroller::serializeDB (/root/reference/src/enroller/enroller_hers.cpp:40-93): normalise in place, then per matrix of
+// `slots` vectors one ciphertext per dimension holding that coordinate of every vector
+void client_hers_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]) {
+    const int dim = cx.prm.dim, Nh = cx.slots;
+    for (size_t v = 0; v < n; v++) normalize(db + v * dim, dim);
+    const ChaChaKey key = make_key(seed);
+    const size_t G = cx.db_cts / dim, ct_elems = (size_t)2 * cx.nQ * cx.N;
+    double *d_rows = (double *)cx.pool.get(sizeof(double) * (size_t)Nh * dim);
+    double *d_slots = (double *)cx.pool.get(sizeof(double) * (size_t)dim * Nh);
+    u64 *d_cts = cx.pool.get(sizeof(u64) * (size_t)dim * ct_elems);
+    for (size_t g = 0; g < G; g++) {
+        const size_t first = g * (size_t)Nh;
+        const size_t rows = n > first ? std::min((size_t)Nh, n - first) : 0;
+        if (rows)
+            HIP_CHECK(hipMemcpyAsync(d_rows, db + first * dim, sizeof(double) * rows * dim, hipMemcpyHostToDevice, cx.stream));
+        hc::hers_pack(cx.stream, d_rows, (long long)rows, dim, Nh, d_slots);
+        encrypt_device(cx, d_slots, dim, key, HY_HERS_NONCE_BASE + g * dim, d_cts);
+        cx.db_store(g * dim, d_cts, dim);
+    }
+    cx.sync();
+    cx.pool.put(d_cts);
+    cx.pool.put((u64 *)d_slots);
+    cx.pool.put((u64 *)d_rows);
+}
+// HersReceiver::encryptQuery (/root/reference/src/receiver/receiver_hers.cpp:13-24): vector_dim ciphertexts
+Ct client_hers_encrypt_query(Context &cx, const double *query, const uint8_t seed[32], uint64_t nonce0) {
+    const int dim = cx.prm.dim, Nh = cx.slots;
+    std::vector<double> qn(query, query + dim);
+    normalize(qn.data(), dim);
+    double *d_q = (double *)cx.pool.get(sizeof(double) * (size_t)dim);
+    double *d_slots = (double *)cx.pool.get(sizeof(double) * (size_t)dim * Nh);
+    HIP_CHECK(hipMemcpyAsync(d_q, qn.data(), sizeof(double) * dim, hipMemcpyHostToDevice, cx.stream));
+    hc::broadcast_rows(cx.stream, d_q, dim, Nh, d_slots);
+    Ct out(&cx, dim, 2, cx.nQ, cx.delta);
+    encrypt_device(cx, d_slots, dim, make_key(seed), nonce0, out.d);
+    cx.sync();  // qn is a stack-owned buffer
+    cx.pool.put((u64 *)d_slots);
+    cx.pool.put((u64 *)d_q);
+    return out;
 }
 
 }  // namespace hydia

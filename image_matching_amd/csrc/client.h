@@ -9,4 +9,7 @@ Ct client_encrypt(Context &cx, const double *slots, int count, const uint8_t see
 Ct client_encrypt_query(Context &cx, const double *query, const uint8_t seed[32], uint64_t nonce);
 void client_decrypt(Context &cx, const Ct &ct, double *out);
 void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]);
+// HERS (approach 4): column-packed enrolment and the vector_dim broadcast query ciphertexts
+void client_hers_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]);
+Ct client_hers_encrypt_query(Context &cx, const double *query, const uint8_t seed[32], uint64_t nonce0);
 }  // namespace hydia

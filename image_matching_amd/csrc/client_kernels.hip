@@ -263,6 +263,18 @@ __global__ __launch_bounds__(256) void k_diag_pack(const double *__restrict__ db
     slots[(size_t)i * Nh + s] = v < rows_left ? dbg[(size_t)v * dim + (r + i) % dim] : 0.0;
 }
 
+// HersEnroller::serializeDBThread (/root/reference/src/enroller/enroller_hers.cpp:108-113): slots[j][k] = db[m*S + k][j].
+// grid (Nh/256, dim)
+__global__ __launch_bounds__(256) void k_hers_pack(const double *__restrict__ dbg, long long rows_left, int dim, int Nh,
+                                                   double *__restrict__ slots) {
+    const int k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    slots[(size_t)j * Nh + k] = k < rows_left ? dbg[(size_t)k * dim + j] : 0.0;
+}
+// HersReceiver::encryptQueryThread (/root/reference/src/receiver/receiver_hers.cpp:58-63): every slot = coordinate i
+__global__ __launch_bounds__(256) void k_broadcast_rows(const double *__restrict__ vals, int Nh, double *__restrict__ slots) {
+    slots[(size_t)blockIdx.y * Nh + blockIdx.x * 256 + threadIdx.x] = vals[blockIdx.y];
+}
+
 }  // namespace
 
 namespace hc {
@@ -323,6 +335,12 @@ void decode(hipStream_t st, const ModC *mod, const u64 *t, int nu, int N, int X,
     for (int len = 2; len <= Nh; len <<= 1)
         hipLaunchKernelGGL(k_fft_fwd_stage, dim3(Nh / 2 / 256, X), dim3(256), 0, st, work, Nh, len, M, rot_group, ksi);
     hipLaunchKernelGGL(k_complex_real, dim3(Nh / 256, X), dim3(256), 0, st, work, out, Nh);
+}
+void hers_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots) {
+    hipLaunchKernelGGL(k_hers_pack, dim3(Nh / 256, dim), dim3(256), 0, st, dbg, rows_left, dim, Nh, slots);
+}
+void broadcast_rows(hipStream_t st, const double *vals, int dim, int Nh, double *slots) {
+    hipLaunchKernelGGL(k_broadcast_rows, dim3(Nh / 256, dim), dim3(256), 0, st, vals, Nh, slots);
 }
 void diag_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots) {
     hipLaunchKernelGGL(k_diag_pack, dim3(Nh / 256, dim), dim3(256), 0, st, dbg, rows_left, dim, Nh, slots);

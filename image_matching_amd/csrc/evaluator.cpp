@@ -409,7 +409,7 @@ Ct Context::rotate_query(const Ct &qc) {
 }
 // computeSimilarity (sender_diag.cpp:12-33): all G blocks of the resident DB in one tensor-accumulate launch
 Ct Context::similarity(const Ct &qc) {
-    if (!d_db || db_cts == 0) throw std::runtime_error("hydia: no database resident");
+    if (!d_db || db_cts == 0 || db_kind != 5) throw std::runtime_error("hydia: no database resident (diagonal packing)");
     if (qc.nl != nQ) throw std::runtime_error("hydia: query must be a fresh (level 0) ciphertext");
     const int dim = prm.dim;
     const int G = (int)(db_cts / dim);
@@ -586,6 +586,35 @@ Ct Context::sum_and_evalsum(const Ct &s) {
         add_inplace(m, t);
     }
     return m;
+}
+
+// ------------------------------------------------------------------ HERS sender (approach 4)
+// HersSender::computeSimilarity / computeSimilarityHelper (/root/reference/src/sender/sender_hers.cpp:13-87): per block the
+// dim products EvalMultNoRelin(query_i, db[m][i]) are relinearised and rescaled ONE BY ONE ("to match HERS paper approach",
+// :73-75) and then summed — run here as one batch of dim ciphertexts per block.
+Ct Context::hers_similarity(const Ct &qc) {
+    if (!d_db || db_cts == 0 || db_kind != 4) throw std::runtime_error("hydia: no database resident (HERS column packing)");
+    const int dim = prm.dim;
+    if (qc.X != dim || qc.npoly != 2 || qc.nl != nQ || !qc.compact())
+        throw std::runtime_error("hydia: HERS query must be vector_dim fresh ciphertexts");
+    const int G = (int)(db_cts / dim);
+    Ct out(this, G, 2, nQ - 1, qc.scale * delta / (double)q[nQ - 1]);
+    Ct dbp(this, dim, 2, nQ, delta);
+    for (int m = 0; m < G; m++) {
+        db_fetch((size_t)m * dim, dbp.d, dim);
+        Ct prod = mult_norelin(qc, dbp);
+        relin_rescale(prod);
+        hk::batch_sum(stream, d_mod, N, prod.d, out.d + (size_t)m * out.ct_elems(), dim, 2, prod.nl);
+    }
+    return out;
+}
+Ct Context::hers_index_scenario(const Ct &qc) {  // sender_hers.cpp:28-40
+    Ct s = hers_similarity(qc);
+    return chebyshev_compare(s, 0.44, 10);
+}
+Ct Context::hers_membership_scenario(const Ct &qc) {  // sender_hers.cpp:43-58
+    Ct s = hers_index_scenario(qc);
+    return sum_and_evalsum(s);
 }
 
 }  // namespace hydia

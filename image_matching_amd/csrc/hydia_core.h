@@ -119,6 +119,7 @@ struct Context : HostParams {
     // 48-bit residues when every scaling prime is below 2^48; HYDIA_DB_UNPACKED keeps plain [2][nQ][N] u64)
     unsigned char *d_db = nullptr;
     size_t db_vectors = 0, db_cts = 0;
+    int db_kind = 0;   // 0 none, 5 diagonal packing (HyDia, approach 5), 4 column packing (HERS, approach 4)
     bool db_packed = true;
     DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }
     void db_store(size_t t0, const u64 *d_plain, int X);  // [X][2][nQ][N] device residues -> ciphertexts t0..t0+X-1
@@ -179,6 +180,10 @@ struct Context : HostParams {
     Ct index_scenario(const Ct &q);
     Ct membership_scenario(const Ct &q);
     Ct sum_and_evalsum(const Ct &s);  // EvalAddMany over the batch + EvalSum over all slots
+    // ---- HERS sender (approach 4, src/sender/sender_hers.cpp): q = dim query ciphertexts
+    Ct hers_similarity(const Ct &q);
+    Ct hers_index_scenario(const Ct &q);
+    Ct hers_membership_scenario(const Ct &q);
 
     // timing of named kernels (HIP events on `stream`)
     void timer_begin(const char *name);

@@ -117,6 +117,8 @@ void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t src_oute
                 int nlimbs);
 // o[x][p][j] = sum_t src_t[x][p][j] * c[t][j] (+ c0[j] on p = 0): X cts of npoly polys, nl limbs, compact output
 void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl);
+// o[p][j] = sum_x in[x][p][j] mod q_j: EvalAdd chain over a batch (HERS sums its 512 per-dimension products); o compact
+void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl);
 // (a0 b0, a0 b1 + a1 b0, a1 b1) for X ciphertext pairs at nl limbs; o: [X][3][nl][N]
 void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls);
 

@@ -162,6 +162,24 @@ __global__ __launch_bounds__(256) void k_lincomb(const ModC *__restrict__ mod, i
     r.y = reduce64(ay, M);
     *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * nl * N + i) = r;
 }
+// grid (N/512, nl, npoly): serial sum over the batch with 128-bit accumulators (X * 2^60 fits)
+__global__ __launch_bounds__(256) void k_batch_sum(const ModC *__restrict__ mod, int N, const u64 *__restrict__ in,
+                                                   u64 *__restrict__ o, int X, int npoly, int nl) {
+    const int j = blockIdx.y, p = blockIdx.z;
+    const ModC M = mod[j];
+    const size_t i = ((size_t)p * nl + j) * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t xs = (size_t)npoly * nl * N;
+    u128 ax = 0, ay = 0;
+    for (int x = 0; x < X; x++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(in + (size_t)x * xs + i);
+        ax += v.x;
+        ay += v.y;
+    }
+    ulonglong2 r;
+    r.x = reduce128(ax, M);
+    r.y = reduce128(ay, M);
+    *reinterpret_cast<ulonglong2 *>(o + i) = r;
+}
 __global__ __launch_bounds__(256) void k_add_scalar(const ModC *__restrict__ mod, int N, u64 *__restrict__ a,
                                                     size_t outer, LimbSel sel, ScaleSel c) {
     const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n;
@@ -548,6 +566,9 @@ void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, in
 }
 void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl) {
     hipLaunchKernelGGL(k_lincomb, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, npoly, nl);
+}
+void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl) {
+    hipLaunchKernelGGL(k_batch_sum, dim3(N / 512, nl, npoly), dim3(256), 0, st, mod, N, in, o, X, npoly, nl);
 }
 void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,
                 const ScaleSel &c) {

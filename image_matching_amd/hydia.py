@@ -98,6 +98,11 @@ def load_library():
         "hydia_membership_scenario": (i32, [vp, vp, pp]),
         "hydia_chebyshev_compare": (i32, [vp, vp, dbl, sz, pp]),
         "hydia_sum_and_evalsum": (i32, [vp, vp, pp]),
+        "hydia_hers_db_enroll": (i32, [vp, vp, sz, vp]),
+        "hydia_hers_encrypt_query": (i32, [vp, vp, vp, u64, pp]),
+        "hydia_hers_compute_similarity": (i32, [vp, vp, pp]),
+        "hydia_hers_index_scenario": (i32, [vp, vp, pp]),
+        "hydia_hers_membership_scenario": (i32, [vp, vp, pp]),
         "hydia_ntt": (i32, [vp, vp, u32, u32, i32]),
         "hydia_eval_rotate": (i32, [vp, vp, i32, pp]),
         "hydia_eval_mult": (i32, [vp, vp, vp, pp]),
@@ -433,3 +438,40 @@ class DiagonalSender:
 
     def indexScenario(self, query_cipher):
         return self.cc._out(self.cc.L.hydia_index_scenario, query_cipher.h)
+
+
+# ---- HERS, approach 4: include/enroller_hers.h:16-37, include/receiver_hers.h:9-28, include/sender_hers.h:9-44
+class HersEnroller:
+    def __init__(self, cc, num_vectors):
+        self.cc, self.numVectors = cc, num_vectors
+
+    def serializeDB(self, database, seed=0):
+        """HersEnroller::serializeDB (src/enroller/enroller_hers.cpp:40-93): index-batched packing, normalises in place."""
+        assert database.dtype == np.float64 and database.flags.c_contiguous
+        assert database.shape == (self.numVectors, self.cc.dim)
+        _chk(self.cc.L.hydia_hers_db_enroll(self.cc.h, _p(database), self.numVectors, _p(_seed(seed))))
+
+
+class HersReceiver(DiagonalReceiver):
+    """HersReceiver::encryptQuery (src/receiver/receiver_hers.cpp:13-24); decrypt* are the shared ones (:26-54)."""
+
+    def encryptQuery(self, query, seed=0, nonce=1000):
+        query = np.ascontiguousarray(query, dtype=np.float64)
+        assert query.shape == (self.cc.dim,)
+        return self.cc._out(self.cc.L.hydia_hers_encrypt_query, _p(query), _p(_seed(seed)), nonce)
+
+
+class HersSender:
+    """include/sender_hers.h:9-44 — computeSimilarity / membershipScenario / indexScenario of approach 4."""
+
+    def __init__(self, cc, num_vectors):
+        self.cc, self.numVectors = cc, num_vectors
+
+    def computeSimilarity(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_hers_compute_similarity, query_cipher.h)
+
+    def membershipScenario(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_hers_membership_scenario, query_cipher.h)
+
+    def indexScenario(self, query_cipher):
+        return self.cc._out(self.cc.L.hydia_hers_index_scenario, query_cipher.h)

@@ -147,6 +147,18 @@ int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *in, double delta, si
 /* multi-GPU membership tail: sum the batch into one ciphertext, then EvalSum over all slots (:46-47) */
 int hydia_sum_and_evalsum(hydia_ctx *ctx, const hydia_ct *in, hydia_ct **out);
 
+/* ---- HERS, approach 4: the paper's main comparison on the same kernels ---- */
+/* HersEnroller::serializeDB, src/enroller/enroller_hers.cpp:40-93: index-batched (column) packing, vector_dim ciphertexts per
+ * `slots`-vector matrix, normalises db IN PLACE; replaces the resident database */
+int hydia_hers_db_enroll(hydia_ctx *ctx, double *db /* n x vector_dim */, size_t n, const uint8_t seed[32]);
+/* HersReceiver::encryptQuery, src/receiver/receiver_hers.cpp:13-24: vector_dim ciphertexts, coordinate i in every slot */
+int hydia_hers_encrypt_query(hydia_ctx *ctx, const double *query, const uint8_t seed[32], uint64_t nonce0, hydia_ct **out);
+/* HersSender::computeSimilarity / indexScenario / membershipScenario, src/sender/sender_hers.cpp:13-58
+ * (relinearise + rescale after every one of the vector_dim products of a block, :70-75) */
+int hydia_hers_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+int hydia_hers_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+int hydia_hers_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+
 /* ---- evaluator primitives (used by the parity tests and by adapters) ---- */
 int hydia_ntt(hydia_ctx *ctx, uint64_t *data /* host, [count][N] in place */, uint32_t count, uint32_t modulus_index,
               int inverse);

@@ -226,4 +226,71 @@ class DiagonalEnroller {
     uint8_t seed[32];
 };
 
+// ---- HERS, approach 4: include/sender_hers.h:9-44, include/receiver_hers.h:9-28, include/enroller_hers.h:16-37.
+// The query is vector_dim ciphertexts (one batch handle, split per element like the reference's vector).
+class HersSender : public Sender {
+  public:
+    HersSender(CryptoContext ccParam, size_t vectorParam) : Sender(std::move(ccParam), vectorParam) {}
+    std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) override {
+        hydia_ct *out = nullptr;
+        if (queryCipher.empty() || !queryCipher[0] ||
+            !cc->check(hydia_hers_compute_similarity(cc->h, queryCipher[0].batch->h, &out), "computeSimilarity"))
+            return {};
+        return split_batch(cc, out);
+    }
+    Ciphertext membershipScenario(std::vector<Ciphertext> &queryCipher) override {
+        hydia_ct *out = nullptr;
+        if (queryCipher.empty() || !queryCipher[0] ||
+            !cc->check(hydia_hers_membership_scenario(cc->h, queryCipher[0].batch->h, &out), "membershipScenario"))
+            return Ciphertext{};
+        return split_batch(cc, out)[0];
+    }
+    std::vector<Ciphertext> indexScenario(std::vector<Ciphertext> &queryCipher) override {
+        hydia_ct *out = nullptr;
+        if (queryCipher.empty() || !queryCipher[0] ||
+            !cc->check(hydia_hers_index_scenario(cc->h, queryCipher[0].batch->h, &out), "indexScenario"))
+            return {};
+        return split_batch(cc, out);
+    }
+};
+class HersQueryReceiver : public HersReceiver {  // HersReceiver with its own encryptQuery (receiver_hers.cpp:13-24)
+  public:
+    HersQueryReceiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
+        : HersReceiver(std::move(ccParam), vectorParam) {
+        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0xC3 ^ i);
+    }
+    std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
+        hydia_ct *out = nullptr;
+        if (query.size() < cc->info.vector_dim) query.resize(cc->info.vector_dim, 0.0);
+        nonce += cc->info.vector_dim;
+        if (!cc->check(hydia_hers_encrypt_query(cc->h, query.data(), seed, nonce, &out), "encryptQuery")) return {};
+        return split_batch(cc, out);
+    }
+
+  private:
+    uint8_t seed[32];
+    uint64_t nonce = 0;
+};
+class HersEnroller {
+  public:
+    HersEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
+        : cc(std::move(ccParam)), numVectors(vectorParam) {
+        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0x3C ^ i);
+    }
+    void serializeDB(std::vector<std::vector<double>> &database) {  // enroller_hers.cpp:40-93
+        const size_t dim = cc->info.vector_dim;
+        std::vector<double> flat(numVectors * dim, 0.0);
+        for (size_t i = 0; i < numVectors && i < database.size(); i++)
+            for (size_t j = 0; j < dim && j < database[i].size(); j++) flat[i * dim + j] = database[i][j];
+        if (!cc->check(hydia_hers_db_enroll(cc->h, flat.data(), numVectors, seed), "serializeDB")) return;
+        for (size_t i = 0; i < numVectors && i < database.size(); i++)
+            for (size_t j = 0; j < dim && j < database[i].size(); j++) database[i][j] = flat[i * dim + j];
+    }
+
+  protected:
+    CryptoContext cc;
+    size_t numVectors;
+    uint8_t seed[32];
+};
+
 }  // namespace hydia

@@ -149,6 +149,14 @@ hy_ct *hyo_membership_scenario(const hy_params *p, const hy_keys *k, const hy_ct
 int hyo_decrypt_membership(const hy_params *p, const hy_keys *k, const hy_ct *c);
 size_t hyo_decrypt_index(const hy_params *p, const hy_keys *k, hy_ct **cts, size_t n_cts, size_t *out,
                          size_t cap);
+/* ---- HERS (approach 4): src/{enroller,receiver,sender}/..._hers.cpp ---- */
+void hyo_hers_layout_row(const hy_params *p, const double *db_norm, size_t n, size_t t, double *slots);
+hy_ct **hyo_hers_enroll(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts);
+hy_ct **hyo_hers_encrypt_query(const hy_params *p, const hy_keys *k, const double *query, const uint8_t seed[32], u64 nonce0);
+hy_ct *hyo_hers_similarity_block(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db_block);
+hy_ct **hyo_hers_compute_similarity(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db, size_t n, size_t *n_out);
+hy_ct **hyo_hers_index_scenario(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db, size_t n, size_t *n_out);
+hy_ct *hyo_hers_membership_scenario(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db, size_t n);
 hy_ct *hyo_ct_at(hy_ct **arr, size_t i);
 void hyo_ct_array_free(hy_ct **arr, size_t n);
 int hyo_num_threads(void);

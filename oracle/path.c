@@ -411,6 +411,107 @@ hy_ct *hyo_membership_scenario(const hy_params *p, const hy_keys *k, const hy_ct
     return m;
 }
 
+/* ------------------------------------------------------------------ HERS (approach 4), SURVEY §8f-4
+ * The paper's main comparison on the same primitives: index-batched (column) packing, one query ciphertext per
+ * dimension, relinearise + rescale after EVERY product.
+ *   HersEnroller::serializeDB / encryptDBThread   /root/reference/src/enroller/enroller_hers.cpp:40-121
+ *   HersReceiver::encryptQuery / encryptQueryThread  /root/reference/src/receiver/receiver_hers.cpp:13-24, :58-63
+ *   HersSender::computeSimilarity / Helper / Serial  /root/reference/src/sender/sender_hers.cpp:13-98 */
+#define HERS_NONCE_BASE (1ull << 37)
+/* ciphertext (m, j): slot k holds coordinate j of database vector m*slots + k (enroller_hers.cpp:108-113) */
+void hyo_hers_layout_row(const hy_params *p, const double *db, size_t n, size_t t, double *slots) {
+    size_t dim = p->dim, S = p->slots, m = t / dim, j = t % dim;
+    for (size_t k = 0; k < S; k++) {
+        size_t v = m * S + k;
+        slots[k] = v < n ? db[v * dim + j] : 0.0;
+    }
+}
+hy_ct **hyo_hers_enroll(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts) {
+    size_t dim = p->dim;
+#pragma omp parallel for
+    for (size_t v = 0; v < n; v++) hyo_normalize(db + v * dim, (int)dim); /* enroller_hers.cpp:75-78 */
+    size_t G = (n + p->slots - 1) / p->slots, T = G * dim;               /* :59-60 */
+    hy_ct **out = (hy_ct **)calloc(T, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+    for (size_t t = 0; t < T; t++) {
+        double *slots = (double *)malloc(sizeof(double) * p->slots);
+        hyo_hers_layout_row(p, db, n, t, slots);
+        out[t] = hyo_encrypt(p, k, slots, p->slots, seed, HERS_NONCE_BASE + t);
+        free(slots);
+    }
+    *n_cts = T;
+    return out;
+}
+/* one ciphertext per dimension, the normalised coordinate broadcast to every slot (receiver_hers.cpp:13-24, :58-63) */
+hy_ct **hyo_hers_encrypt_query(const hy_params *p, const hy_keys *k, const double *query, const uint8_t seed[32], u64 nonce0) {
+    int dim = p->dim;
+    double *qn = (double *)malloc(sizeof(double) * dim);
+    memcpy(qn, query, sizeof(double) * dim);
+    hyo_normalize(qn, dim);
+    hy_ct **out = (hy_ct **)calloc(dim, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < dim; i++) {
+        double *v = (double *)malloc(sizeof(double) * p->slots);
+        for (int s = 0; s < p->slots; s++) v[s] = qn[i];
+        out[i] = hyo_encrypt(p, k, v, p->slots, seed, nonce0 + (u64)i);
+        free(v);
+    }
+    free(qn);
+    return out;
+}
+/* computeSimilarityHelper (sender_hers.cpp:62-87): EvalMultNoRelin, Relinearize, Rescale per dimension, then the sum */
+hy_ct *hyo_hers_similarity_block(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db_block) {
+    int dim = p->dim;
+    hy_ct **score = (hy_ct **)calloc(dim, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < dim; i++) {
+        score[i] = hyo_mult_norelin(p, q[i], db_block[i]);
+        hyo_relin_inplace(p, k, score[i]);
+        hyo_rescale_inplace(p, score[i]);
+    }
+    for (int i = 1; i < dim; i++) {
+        hyo_add_inplace(p, score[0], score[i]);
+        hyo_ct_free(score[i]);
+    }
+    hy_ct *acc = score[0];
+    free(score);
+    return acc;
+}
+hy_ct **hyo_hers_compute_similarity(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db, size_t n, size_t *n_out) {
+    size_t G = (n + p->slots - 1) / p->slots; /* sender_hers.cpp:16 */
+    hy_ct **sim = (hy_ct **)calloc(G, sizeof(hy_ct *));
+    for (size_t m = 0; m < G; m++) sim[m] = hyo_hers_similarity_block(p, k, q, db + m * p->dim);
+    *n_out = G;
+    return sim;
+}
+/* indexScenario / membershipScenario of HersSender (sender_hers.cpp:28-58): same tails as the diagonal sender */
+hy_ct **hyo_hers_index_scenario(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db, size_t n, size_t *n_out) {
+    hy_ct **score = hyo_hers_compute_similarity(p, k, q, db, n, n_out);
+#pragma omp parallel for
+    for (size_t i = 0; i < *n_out; i++) {
+        hy_ct *c = hyo_chebyshev_compare(p, k, score[i], MATCH_THRESHOLD, COMP_DEPTH);
+        hyo_ct_free(score[i]);
+        score[i] = c;
+    }
+    return score;
+}
+hy_ct *hyo_hers_membership_scenario(const hy_params *p, const hy_keys *k, hy_ct **q, hy_ct **db, size_t n) {
+    size_t G;
+    hy_ct **score = hyo_hers_index_scenario(p, k, q, db, n, &G);
+    hy_ct *m = score[0];
+    for (size_t i = 1; i < G; i++) {
+        hyo_add_inplace(p, m, score[i]);
+        hyo_ct_free(score[i]);
+    }
+    free(score);
+    for (int r = 1; r < p->slots; r <<= 1) {
+        hy_ct *t = hyo_rotate(p, k, m, r);
+        hyo_add_inplace(p, m, t);
+        hyo_ct_free(t);
+    }
+    return m;
+}
+
 hy_ct *hyo_ct_at(hy_ct **arr, size_t i) { return arr[i]; }
 void hyo_ct_array_free(hy_ct **arr, size_t n) {
     for (size_t i = 0; i < n; i++) hyo_ct_free(arr[i]);

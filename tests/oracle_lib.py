@@ -92,6 +92,12 @@ def lib():
         "hyo_membership_scenario": (vp, [vp, vp, vp, vp, C.c_size_t]),
         "hyo_decrypt_membership": (C.c_int, [vp, vp, vp]),
         "hyo_decrypt_index": (C.c_size_t, [vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
+        "hyo_hers_layout_row": (None, [vp, vp, C.c_size_t, C.c_size_t, vp]),
+        "hyo_hers_enroll": (vp, [vp, vp, vp, C.c_size_t, vp, vp]),
+        "hyo_hers_encrypt_query": (vp, [vp, vp, vp, vp, C.c_uint64]),
+        "hyo_hers_compute_similarity": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
+        "hyo_hers_index_scenario": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
+        "hyo_hers_membership_scenario": (vp, [vp, vp, vp, vp, C.c_size_t]),
         "hyo_ct_at": (vp, [vp, C.c_size_t]),
         "hyo_ct_array_free": (None, [vp, C.c_size_t]),
         "hyo_num_threads": (C.c_int, []),
@@ -391,6 +397,31 @@ class Oracle:
 
     def membership_scenario(self, q, db, n):
         return Ct(self.P, self.L.hyo_membership_scenario(self.P.h, self.K.h, q.h, db.h, n))
+
+    # ---- HERS (approach 4)
+    def hers_enroll(self, db, seed):
+        assert db.dtype == np.float64 and db.flags.c_contiguous and db.shape[1] == self.P.dim
+        n_out = C.c_size_t(0)
+        h = self.L.hyo_hers_enroll(self.P.h, self.K.h, _ptr(db), db.shape[0], _ptr(seed_bytes(seed)), C.byref(n_out))
+        return CtArray(self.P, h, n_out.value)
+
+    def hers_encrypt_query(self, query, seed, nonce0=1000):
+        query = np.ascontiguousarray(query, dtype=np.float64)
+        h = self.L.hyo_hers_encrypt_query(self.P.h, self.K.h, _ptr(query), _ptr(seed_bytes(seed)), nonce0)
+        return CtArray(self.P, h, self.P.dim)
+
+    def hers_compute_similarity(self, q, db, n):
+        n_out = C.c_size_t(0)
+        h = self.L.hyo_hers_compute_similarity(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
+        return CtArray(self.P, h, n_out.value)
+
+    def hers_index_scenario(self, q, db, n):
+        n_out = C.c_size_t(0)
+        h = self.L.hyo_hers_index_scenario(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
+        return CtArray(self.P, h, n_out.value)
+
+    def hers_membership_scenario(self, q, db, n):
+        return Ct(self.P, self.L.hyo_hers_membership_scenario(self.P.h, self.K.h, q.h, db.h, n))
 
     def decrypt_membership(self, ct):
         return bool(self.L.hyo_decrypt_membership(self.P.h, self.K.h, ct.h))

@@ -167,6 +167,64 @@ def test_cli_image_matching_on_reference_dataset(tmp_path):
     assert "Membership scenario: true" in out.stdout and "Index scenario: [ 0 ]" in out.stdout
     row = (tmp_path / "latency.csv").read_text().strip().split(",")
     assert row[0] == "Diagonal" and row[1] == "1024" and row[10] == "true" and row[11] == "[ 0 ]"
-    # approaches 1-4 are not part of this framework: explicit refusal, no silent fallback
-    out = subprocess.run([exe, str(dat), "4"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    # approach 4 (HERS) on the same stack
+    out = subprocess.run([exe, str(dat), "4"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Membership scenario: true" in out.stdout and "Index scenario: [ 0 ]" in out.stdout
+    # approaches 1-3 are not part of this framework: explicit refusal, no silent fallback
+    out = subprocess.run([exe, str(dat), "3"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "only approach 5" in out.stderr
+
+
+@pytest.mark.parametrize("n,matches", [(1300, [0, 1299]), (5, [2])])
+def test_hers_bit_exact_small_ring(im, small, n, matches):
+    """Approach 4 (HERS): enrolment, the vector_dim query ciphertexts, similarity, index and membership on
+    the GPU, bit exact against the oracle's restatement of src/{enroller,receiver,sender}/*_hers.cpp."""
+    P, K, Or, cc = small
+    rng = np.random.default_rng(n + 7)
+    db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
+    for i in matches:
+        db[i] = rng.integers(1, 4, size=P.dim)
+    query = np.ones(P.dim)
+    a, b = db.copy(), db.copy()
+    dbc = Or.hers_enroll(a, 4)
+    im.HersEnroller(cc, n).serializeDB(b, seed=4)
+    assert np.array_equal(a, b) and cc.db_stats()[1] == len(dbc)
+    for t in sorted(set([0, 3, len(dbc) - 1])):
+        assert np.array_equal(cc.db_export_ct(t), dbc[t].data()), t
+    q = Or.hers_encrypt_query(query, 6, 1000)
+    gq = im.HersReceiver(cc, n).encryptQuery(query, seed=6, nonce=1000)
+    gqd = gq.export()
+    for i in (0, 1, P.dim - 1):
+        assert np.array_equal(gqd[i], q[i].data()), i
+    sender = im.HersSender(cc, n)
+    sim, gsim = Or.hers_compute_similarity(q, dbc, n), sender.computeSimilarity(gq).export()
+    for g in range(len(sim)):
+        assert np.array_equal(gsim[g], sim[g].data())
+    idx, gidx = Or.hers_index_scenario(q, dbc, n), sender.indexScenario(gq)
+    assert np.array_equal(gidx.export()[0], idx[0].data())
+    # (small vector_dim: a random row may legitimately clear 0.44, so the expectation is the oracle's own decryption)
+    found = im.DiagonalReceiver(cc, n).decryptIndex(gidx)
+    assert found == Or.decrypt_index(idx) and set(matches) <= set(found)
+    mem, gmem = Or.hers_membership_scenario(q, dbc, n), sender.membershipScenario(gq)
+    assert np.array_equal(gmem.export()[0], mem.data())
+    # the diagonal sender refuses a column-packed database (and vice versa): no silent mixing of layouts
+    with pytest.raises(im.HydiaError):
+        im.DiagonalSender(cc, n).computeSimilarity(im.DiagonalReceiver(cc, n).encryptQuery(query, seed=1, nonce=1))
+
+
+def test_hers_reference_dataset_full_ring(im):
+    """./ImageMatching ../test/2_10.dat 4 on the GPU: expected `true`, `[0]`, scores within 1e-4 of plaintext cosine."""
+    cc = im.Context()
+    cc.keygen(5)
+    g = np.load(os.path.join(GOLDEN, "dataset_2_10.npz"))
+    n, query, db = int(g["n"]), g["query"].astype(np.float64), g["db"].astype(np.float64)
+    im.HersEnroller(cc, n).serializeDB(db, seed=9)
+    receiver, sender = im.HersReceiver(cc, n), im.HersSender(cc, n)
+    qc = receiver.encryptQuery(query, seed=5)
+    assert len(qc) == 512
+    scores = cc.decrypt(sender.computeSimilarity(qc))[0]
+    assert np.abs(scores[:n] - g["cosine"]).max() < TOL and np.abs(scores[n:]).max() < TOL
+    assert receiver.decryptMembership(sender.membershipScenario(qc)) is True
+    assert receiver.decryptIndex(sender.indexScenario(qc)) == [0]
+    cc.close()

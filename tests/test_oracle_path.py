@@ -108,3 +108,30 @@ def test_compare_guard_and_plain_curve(small_params, small_keys):
         o = Or.decrypt(Or.chebyshev_compare(ct, 0.44, depth))
         r = np.array([P.L.hyo_compare_plain(float(v), 0.44, degree) for v in x])
         assert np.abs(o - r).max() < TOL
+
+
+@pytest.mark.parametrize("n,matches", [(1300, [0, 1299]), (5, [2])])
+def test_hers_path_small_ring(small_params, small_keys, n, matches):
+    """Approach 4 (HERS) on the oracle: column packing, one query ciphertext per dimension, relin + rescale per
+    product — same scores and decisions as plaintext cosine."""
+    P, Or = small_params, O.Oracle(small_params, small_keys)
+    rng = np.random.default_rng(n)
+    db = synth_db(rng, n, P.dim, matches)
+    query = np.ones(P.dim)
+    cos = cosine(db, query)
+    dbc = Or.hers_enroll(db.copy(), 4)
+    G = -(-n // P.slots)
+    assert len(dbc) == G * P.dim
+    q = Or.hers_encrypt_query(query, 6)
+    assert len(q) == P.dim
+    sim = Or.hers_compute_similarity(q, dbc, n)
+    scores = np.concatenate([Or.decrypt(sim[i]) for i in range(G)])
+    assert np.abs(scores[:n] - cos).max() < TOL and (n == len(scores) or np.abs(scores[n:]).max() < TOL)
+    assert Or.decrypt_index(Or.hers_index_scenario(q, dbc, n)) == sorted(matches)
+    assert Or.decrypt_membership(Or.hers_membership_scenario(q, dbc, n)) is True
+    # layout: slot k of ciphertext (m, j) is coordinate j of vector m*slots + k (enroller_hers.cpp:108-113)
+    slots = np.zeros(P.slots)
+    dbn = db / np.linalg.norm(db, axis=1, keepdims=True)
+    P.L.hyo_hers_layout_row(P.h, dbn.ctypes.data, n, (G - 1) * P.dim + 3, slots.ctypes.data)
+    k = min(n - (G - 1) * P.slots, P.slots) - 1
+    assert slots[k] == dbn[(G - 1) * P.slots + k, 3] and (k + 1 == P.slots or slots[k + 1] == 0.0)
