@@ -369,6 +369,22 @@ Ct Context::mult_norelin(const Ct &a, const Ct &b) {
     hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl, a.lstride, b.lstride);
     return o;
 }
+// EvalMultNoRelin with c (2 components, same limbs) leaving at the product's scale: d0,d1 -= (K/2 mod q_j) * c0,c1 where
+// K = round(s_a*s_b/s_c); the caller's doubling relinearisation turns that into 2ab - K*c
+Ct Context::mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c) {
+    if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2 || c.X != a.X || c.npoly != 2 || c.nl != a.nl)
+        throw std::runtime_error("hydia: mult-sub shape mismatch");
+    Ct o(this, a.X, 3, a.nl, a.scale * b.scale);
+    const u64 K = (u64)std::llround(o.scale / c.scale);
+    ScaleSel kap{};
+    for (int j = 0; j < a.nl; j++) {
+        const u64 inv2 = (q[j] + 1) >> 1;
+        kap.s[j] = mulmod_u64(K % q[j], inv2, q[j]);
+        kap.s_sh[j] = shoup_h(kap.s[j], q[j]);
+    }
+    hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl, a.lstride, b.lstride, c.d, c.lstride, &kap);
+    return o;
+}
 Ct Context::mult(const Ct &a, const Ct &b) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
@@ -429,31 +445,40 @@ struct Cheb {
     std::vector<Ct> T;  // T[1..8]
     std::vector<Ct> G;  // G[i] = T_{8*2^i}; G[0] is a view of T[8]
 };
-// 2ab - c (c == nullptr: the constant 1): tensor, relinearise (doubling fused into its last pass), rescale (the
-// subtraction fused into its last pass) — same operation order as the oracle: relin, x2, rescale, -c
+// 2ab - c (c == nullptr: the constant 1).  c is brought to the product's scale s_a*s_b by the integer factor
+// K = round(s_a*s_b/s_c) and leaves with the tensor (d -= (K/2 mod q)*c ahead of the doubling relinearisation), so the
+// subtraction joins operands of identical scale; same arithmetic as the oracle's relin, x2, -K*c, rescale.
 Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
-    Ct o = cx->mult_norelin(x, y);
     const double minus_one = -1.0;
-    if (c) cx->relin_rescale(o, true, c, nullptr);
-    else cx->relin_rescale(o, true, nullptr, &minus_one);
+    if (c) {
+        Ct cv = c->alias(nl);
+        Ct o = cx->mult_norelin_sub(x, y, cv);
+        cx->relin_rescale(o, true, nullptr, nullptr);
+        return o;
+    }
+    Ct o = cx->mult_norelin(x, y);
+    cx->relin_rescale(o, true, nullptr, &minus_one);
     return o;
 }
-Ct cheb_leaf(Cheb &ch, const double *c, int deg) {
-    Context *cx = ch.cx;
+int leaf_nl(Cheb &ch, const double *c, int deg) {
     int nl = ch.T[1].nl;
+    for (int j = 1; j <= deg; j++)
+        if (c[j] != 0.0) nl = std::min(nl, ch.T[j].nl);
+    return nl;
+}
+// sum_j c_j T_j + c_0 in one fused pass, every constant encoded at target*q_l/scale(T_j): the rescaled leaf has scale `target`
+Ct cheb_leaf(Cheb &ch, const double *c, int deg, double target) {
+    Context *cx = ch.cx;
+    const int nl = leaf_nl(ch, c, deg);
     bool any = false;
     for (int j = 1; j <= deg; j++)
-        if (c[j] != 0.0) {
-            any = true;
-            nl = std::min(nl, ch.T[j].nl);
-        }
-    const double S = cx->delta * (double)cx->q[nl - 1];
-    // one fused pass: sum_j c_j T_j + c_0 with every constant encoded at S / scale(T_j) (a pure constant is 0*T_1 + c_0)
+        if (c[j] != 0.0) any = true;
+    const double S = target * (double)cx->q[nl - 1];
     std::vector<Ct> views;
     std::vector<double> coef;
-    const int last = any ? deg : 1;
+    const int last = any ? deg : 1;  // a pure constant is 0*T_1 + c_0
     for (int j = 1; j <= last; j++) {
         const double cj = any ? c[j] : 0.0;
         if (cj == 0.0 && any) continue;
@@ -464,24 +489,43 @@ Ct cheb_leaf(Cheb &ch, const double *c, int deg) {
     for (auto &v : views) terms.push_back(&v);
     Ct acc = cx->lincomb(terms, coef, c[0], S);
     cx->rescale(acc);
+    acc.scale = target;
     return acc;
 }
-Ct cheb_node(Cheb &ch, const double *c, int deg, int gi) {
-    Context *cx = ch.cx;
-    while (deg > 0 && c[deg] == 0.0) deg--;
-    if (deg < 8) return cheb_leaf(ch, c, deg);
-    const int g = 8 << gi;
-    if (deg < g) return cheb_node(ch, c, deg, gi - 1);
-    std::vector<double> qc(g, 0.0), rc(g, 0.0);
-    for (int j = 0; j < g; j++) rc[j] = c[j];
+void cheb_split(const double *c, int deg, int g, std::vector<double> &qc, std::vector<double> &rc) {
+    qc.assign(g, 0.0);
+    rc.assign(c, c + g);
     qc[0] = c[g];
     for (int j = g + 1; j <= deg; j++) {
         qc[j - g] = 2.0 * c[j];
         rc[2 * g - j] -= c[j];
     }
-    Ct Q = cheb_node(ch, qc.data(), deg - g, gi - 1);
-    Ct R = cheb_node(ch, rc.data(), g - 1, gi - 1);
+}
+int cheb_node_nl(Cheb &ch, const double *c, int deg, int gi) {  // limbs of cheb_node's result (dry run)
+    while (deg > 0 && c[deg] == 0.0) deg--;
+    if (deg < 8) return leaf_nl(ch, c, deg) - 1;
+    const int g = 8 << gi;
+    if (deg < g) return cheb_node_nl(ch, c, deg, gi - 1);
+    std::vector<double> qc, rc;
+    cheb_split(c, deg, g, qc, rc);
+    const int nq = cheb_node_nl(ch, qc.data(), deg - g, gi - 1), nr = cheb_node_nl(ch, rc.data(), g - 1, gi - 1);
+    return std::min(std::min(nq, ch.G[gi].nl) - 1, nr);
+}
+// sum_j c_j T_j at scale `target`; the target is pushed down the Paterson-Stockmeyer tree (quotient: target*q_l/scale(T_g),
+// remainder: the product's scale) so every addition joins operands of identical scale
+Ct cheb_node(Cheb &ch, const double *c, int deg, int gi, double target) {
+    Context *cx = ch.cx;
+    while (deg > 0 && c[deg] == 0.0) deg--;
+    if (deg < 8) return cheb_leaf(ch, c, deg, target);
+    const int g = 8 << gi;
+    if (deg < g) return cheb_node(ch, c, deg, gi - 1, target);
+    std::vector<double> qc, rc;
+    cheb_split(c, deg, g, qc, rc);
+    const int nq = cheb_node_nl(ch, qc.data(), deg - g, gi - 1);
+    const int lp = std::min(nq, ch.G[gi].nl);
+    Ct Q = cheb_node(ch, qc.data(), deg - g, gi - 1, target * (double)cx->q[lp - 1] / ch.G[gi].scale);
     Ct prod = cx->mult(Q, ch.G[gi]);
+    Ct R = cheb_node(ch, rc.data(), g - 1, gi - 1, prod.scale);
     const int nl = std::min(prod.nl, R.nl);
     cx->drop_to(prod, nl);
     cx->drop_to(R, nl);
@@ -535,22 +579,27 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
             gi++;
         }
     }
-    Ct y = cheb_node(ch, c.data(), degree, gi);
+    Ct y = cheb_node(ch, c.data(), degree, gi, delta);
     ch.G.clear();
     ch.T.clear();
     // f4 in depth 4: (c1 y + c3 y^3) + y^4 (c5 y + c7 y^3) + (c9 y) y^8   (openFHE_wrapper.cpp:158-169, :179)
     Ct y2 = mult(y, y), y3 = mult(y2, y), y4 = mult(y2, y2), y8 = mult(y4, y4);
     const int nl = y3.nl;
-    const double S = delta * (double)q[nl - 1];
     Ct yd = y.alias(nl);
-    Ct u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, S);
-    rescale(u);
-    Ct v = lincomb({&yd, &y3}, {F4[5], F4[7]}, 0.0, S);
+    // v at scale Delta; a = v*y^4 fixes the scale the other two summands are steered to
+    Ct v = lincomb({&yd, &y3}, {F4[5], F4[7]}, 0.0, delta * (double)q[nl - 1]);
     rescale(v);
-    const double S0 = delta * (double)q[y.nl - 1];
-    Ct w = lincomb({&y}, {F4[9]}, 0.0, S0);
+    v.scale = delta;
+    Ct a = mult(v, y4);
+    Ct u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, a.scale * (double)q[nl - 1]);
+    rescale(u);
+    u.scale = a.scale;
+    const int lb = std::min(y.nl - 1, y8.nl);
+    const double wt = a.scale * (double)q[lb - 1] / y8.scale;
+    Ct w = lincomb({&y}, {F4[9]}, 0.0, wt * (double)q[y.nl - 1]);
     rescale(w);
-    Ct a = mult(v, y4), b = mult(w, y8);
+    w.scale = wt;
+    Ct b = mult(w, y8);
     const int fl = std::min(std::min(a.nl, b.nl), u.nl);
     drop_to(a, fl);
     drop_to(b, fl);

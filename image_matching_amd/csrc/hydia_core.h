@@ -170,6 +170,7 @@ struct Context : HostParams {
     // sum_t coef[t] * terms[t] + c0 at common scale S (each constant encoded at S / scale(term)); all terms same X, npoly, nl
     Ct lincomb(const std::vector<const Ct *> &terms, const std::vector<double> &coef, double c0, double S);
     Ct mult_norelin(const Ct &a, const Ct &b);
+    Ct mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c);
     Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale
     Ct rotate(const Ct &a, int rot);    // X = any; full key switch
 

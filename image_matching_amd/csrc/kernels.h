@@ -120,7 +120,8 @@ void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, 
 // o[p][j] = sum_x in[x][p][j] mod q_j: EvalAdd chain over a batch (HERS sums its 512 per-dimension products); o compact
 void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl);
 // (a0 b0, a0 b1 + a1 b0, a1 b1) for X ciphertext pairs at nl limbs; o: [X][3][nl][N]
-void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls);
+void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls,
+            const u64 *c = nullptr, int c_ls = 0, const ScaleSel *kap = nullptr);
 
 // ---- key switching
 // out[x][t][c] = sum_s y[x][s][c] * tab.f[s][t] mod q_{dsel.mod[t]} ; y coefficient form, residues < 2^60

@@ -197,9 +197,13 @@ __global__ __launch_bounds__(256) void k_copy_limbs(int N, const u64 *__restrict
     *reinterpret_cast<ulonglong2 *>(dst + (size_t)x * dso + (size_t)slot * N + i) =
         *reinterpret_cast<const ulonglong2 *>(src + (size_t)x * so + (size_t)slot * N + i);
 }
-// EvalMultNoRelin on X pairs: grid (N/512, nl, X); inputs may be limb-strided views, output compact
+// EvalMultNoRelin on X pairs: grid (N/512, nl, X); inputs may be limb-strided views, output compact.
+// SUB: d0 -= kap_j*c0, d1 -= kap_j*c1 for a 2-component c (the comparator's  2ab - K*c  with kap = K/2 mod q_j, applied
+// ahead of the doubling relinearisation)
+template <bool SUB>
 __global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ a,
-                                                const u64 *__restrict__ b, u64 *__restrict__ o, int nl, int a_ls, int b_ls) {
+                                                const u64 *__restrict__ b, u64 *__restrict__ o, int nl, int a_ls, int b_ls,
+                                                const u64 *__restrict__ c, int c_ls, ScaleSel kap) {
     const int j = blockIdx.y, x = blockIdx.z;
     const ModC M = mod[j];
     const size_t i = (size_t)j * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
@@ -213,6 +217,15 @@ __global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, in
     d1.y = reduce128((u128)a0.y * b1.y + (u128)a1.y * b0.y, M);
     d2.x = mulmod(a1.x, b1.x, M);
     d2.y = mulmod(a1.y, b1.y, M);
+    if (SUB) {
+        const size_t pc = (size_t)x * 2 * c_ls * N + i;
+        const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(c + pc), c1 = *reinterpret_cast<const ulonglong2 *>(c + pc + (size_t)c_ls * N);
+        const u64 k = kap.s[j], ks = kap.s_sh[j];
+        d0.x = submod(d0.x, mulmod_shoup(c0.x, k, ks, M.q), M.q);
+        d0.y = submod(d0.y, mulmod_shoup(c0.y, k, ks, M.q), M.q);
+        d1.x = submod(d1.x, mulmod_shoup(c1.x, k, ks, M.q), M.q);
+        d1.y = submod(d1.y, mulmod_shoup(c1.y, k, ks, M.q), M.q);
+    }
     const size_t po = (size_t)x * 3 * ps + i;
     *reinterpret_cast<ulonglong2 *>(o + po) = d0;
     *reinterpret_cast<ulonglong2 *>(o + po + ps) = d1;
@@ -577,8 +590,13 @@ void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, in
 void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t so, size_t dso, int X, int nlimbs) {
     hipLaunchKernelGGL(k_copy_limbs, dim3(N / 512, X * nlimbs), dim3(256), 0, st, N, src, dst, so, dso, nlimbs);
 }
-void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls) {
-    hipLaunchKernelGGL(k_tensor, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl, a_ls, b_ls);
+void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls,
+            const u64 *c, int c_ls, const ScaleSel *kap) {
+    if (c)
+        hipLaunchKernelGGL(k_tensor<true>, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl, a_ls, b_ls, c, c_ls, *kap);
+    else
+        hipLaunchKernelGGL(k_tensor<false>, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl, a_ls, b_ls,
+                           (const u64 *)nullptr, 0, ScaleSel{});
 }
 void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, u64 *out, size_t oo, int X,
                   const ConvTab &tab, const LimbSel &dsel) {

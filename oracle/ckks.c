@@ -650,6 +650,22 @@ hy_ct *hyo_mul_const(const hy_params *p, const hy_ct *a, double c, double const_
     }
     return o;
 }
+/* a -= K * b for an integer K (reduced per limb): aligns b's scale to a's before a subtraction (comparator steps) */
+void hyo_submul_int(const hy_params *p, hy_ct *a, const hy_ct *b, u64 K) {
+    int N = p->N;
+    if (a->nl != b->nl || a->npoly != b->npoly) {
+        fprintf(stderr, "hydia oracle: submul level/shape mismatch\n");
+        return;
+    }
+    PARFOR
+    for (int t = 0; t < a->npoly * a->nl; t++) {
+        int j = t % a->nl;
+        u64 q = p->q[j], r = K % q;
+        u64 *x = a->d + (size_t)t * N;
+        const u64 *y = b->d + (size_t)t * N;
+        for (int c = 0; c < N; c++) x[c] = submod(x[c], mulmod(y[c], r, &p->bq[j]), q);
+    }
+}
 /* ct x ct with level alignment, relinearisation and rescale */
 hy_ct *hyo_mult(const hy_params *p, const hy_keys *k, const hy_ct *a, const hy_ct *b) {
     int nl = a->nl < b->nl ? a->nl : b->nl;

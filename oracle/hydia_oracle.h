@@ -117,6 +117,7 @@ hy_ct *hyo_rotate(const hy_params *p, const hy_keys *k, const hy_ct *c, int rot)
 hy_ct *hyo_mult_norelin(const hy_params *p, const hy_ct *a, const hy_ct *b);
 void hyo_add_inplace(const hy_params *p, hy_ct *a, const hy_ct *b);
 void hyo_sub_inplace(const hy_params *p, hy_ct *a, const hy_ct *b);
+void hyo_submul_int(const hy_params *p, hy_ct *a, const hy_ct *b, u64 K);
 void hyo_relin_inplace(const hy_params *p, const hy_keys *k, hy_ct *a);
 void hyo_rescale_inplace(const hy_params *p, hy_ct *a);
 void hyo_drop_to(const hy_params *p, hy_ct *a, int nl);

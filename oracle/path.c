@@ -68,7 +68,10 @@ typedef struct {
     int ng;
 } cheb_ctx;
 
-/* 2*a*b - c (c may be NULL meaning the constant 1): one ct x ct product, doubled before the rescale */
+/* 2*a*b - c (c may be NULL meaning the constant 1): one ct x ct product, doubled before the rescale.  Scale management:
+ * the product sits at scale s_a*s_b, c at s_c; c is brought to the product's scale by the INTEGER factor
+ * K = round(s_a*s_b/s_c) (about 2^45, relative rounding 1e-14) and subtracted BEFORE the rescale, so both operands of the
+ * subtraction carry the same scale exactly and no drift enters the Chebyshev recurrence. */
 static hy_ct *cheb_step(const hy_params *p, const hy_keys *k, const hy_ct *a, const hy_ct *b, const hy_ct *c) {
     int nl = a->nl < b->nl ? a->nl : b->nl;
     hy_ct *x = hyo_ct_clone(p, a), *y = hyo_ct_clone(p, b);
@@ -79,29 +82,35 @@ static hy_ct *cheb_step(const hy_params *p, const hy_keys *k, const hy_ct *a, co
     hyo_ct_free(y);
     hyo_relin_inplace(p, k, o);
     hyo_add_inplace(p, o, o); /* x2 */
-    hyo_rescale_inplace(p, o);
     if (c) {
         hy_ct *cc = hyo_ct_clone(p, c);
         hyo_drop_to(p, cc, o->nl);
-        hyo_sub_inplace(p, o, cc);
+        hyo_submul_int(p, o, cc, (u64)llround(o->scale / cc->scale));
         hyo_ct_free(cc);
+        hyo_rescale_inplace(p, o);
     } else {
+        hyo_rescale_inplace(p, o);
         hyo_add_const(p, o, -1.0);
     }
     return o;
 }
 
-/* sum_{j<=deg} c_j T_j with deg <= 7: constants encoded so that the rescaled result has scale exactly Delta */
-static hy_ct *cheb_leaf(cheb_ctx *cx, const double *c, int deg) {
-    const hy_params *p = cx->p;
+/* limbs in use by the terms of a leaf (before its rescale) */
+static int leaf_nl(cheb_ctx *cx, const double *c, int deg) {
     int nl = cx->T[1]->nl;
+    for (int j = 1; j <= deg; j++)
+        if (c[j] != 0.0 && cx->T[j]->nl < nl) nl = cx->T[j]->nl;
+    return nl;
+}
+/* sum_{j<=deg} c_j T_j with deg <= 7: constants encoded at target*q_l/scale(T_j) so that the rescaled result has scale
+ * exactly `target` whatever the scales of the T_j */
+static hy_ct *cheb_leaf(cheb_ctx *cx, const double *c, int deg, double target) {
+    const hy_params *p = cx->p;
+    int nl = leaf_nl(cx, c, deg);
     int any = 0;
     for (int j = 1; j <= deg; j++)
-        if (c[j] != 0.0) {
-            any = 1;
-            if (cx->T[j]->nl < nl) nl = cx->T[j]->nl;
-        }
-    double S = p->delta * (double)p->q[nl - 1];
+        if (c[j] != 0.0) any = 1;
+    double S = target * (double)p->q[nl - 1];
     hy_ct *acc = NULL;
     int last = any ? deg : 1; /* a pure constant is encoded as 0*T_1 + c_0 */
     for (int j = 1; j <= last; j++) {
@@ -121,27 +130,52 @@ static hy_ct *cheb_leaf(cheb_ctx *cx, const double *c, int deg) {
     }
     hyo_add_const(p, acc, c[0]);
     hyo_rescale_inplace(p, acc);
+    acc->scale = target;
     return acc;
 }
 
-/* evaluates sum_{j<=deg} c_j T_j, deg < 2*g where g = 8*2^gi (or deg < 8 when gi < 0) */
-static hy_ct *cheb_node(cheb_ctx *cx, const double *c, int deg, int gi) {
-    const hy_params *p = cx->p;
-    while (deg > 0 && c[deg] == 0.0) deg--;
-    if (deg < 8) return cheb_leaf(cx, c, deg);
-    int g = 8 << gi;
-    if (deg < g) return cheb_node(cx, c, deg, gi - 1);
+static void cheb_split(const double *c, int deg, int g, double *qc, double *rc) {
     /* c = q * T_g + r using T_j = 2 T_{j-g} T_g - T_{2g-j}  (g < j < 2g) */
-    double *qc = (double *)calloc(g, sizeof(double)), *rc = (double *)calloc(g, sizeof(double));
-    for (int j = 0; j < g; j++) rc[j] = c[j];
+    for (int j = 0; j < g; j++) {
+        qc[j] = 0.0;
+        rc[j] = c[j];
+    }
     qc[0] = c[g];
     for (int j = g + 1; j <= deg; j++) {
         qc[j - g] = 2.0 * c[j];
         rc[2 * g - j] -= c[j];
     }
-    hy_ct *Q = cheb_node(cx, qc, deg - g, gi - 1);
-    hy_ct *R = cheb_node(cx, rc, g - 1, gi - 1);
+}
+/* limbs the result of cheb_node will have (dry run of the recursion below) */
+static int cheb_node_nl(cheb_ctx *cx, const double *c, int deg, int gi) {
+    while (deg > 0 && c[deg] == 0.0) deg--;
+    if (deg < 8) return leaf_nl(cx, c, deg) - 1;
+    int g = 8 << gi;
+    if (deg < g) return cheb_node_nl(cx, c, deg, gi - 1);
+    double *qc = (double *)calloc(g, sizeof(double)), *rc = (double *)calloc(g, sizeof(double));
+    cheb_split(c, deg, g, qc, rc);
+    int nq = cheb_node_nl(cx, qc, deg - g, gi - 1), nr = cheb_node_nl(cx, rc, g - 1, gi - 1);
+    free(qc);
+    free(rc);
+    int np = (nq < cx->G[gi]->nl ? nq : cx->G[gi]->nl) - 1;
+    return np < nr ? np : nr;
+}
+/* evaluates sum_{j<=deg} c_j T_j at scale `target`, deg < 2*g where g = 8*2^gi (or deg < 8 when gi < 0).  The target
+ * scale is pushed DOWN the recursion (quotient: target*q_l/scale(T_g); remainder: the product's scale), so every
+ * addition in the tree joins operands of identical scale. */
+static hy_ct *cheb_node(cheb_ctx *cx, const double *c, int deg, int gi, double target) {
+    const hy_params *p = cx->p;
+    while (deg > 0 && c[deg] == 0.0) deg--;
+    if (deg < 8) return cheb_leaf(cx, c, deg, target);
+    int g = 8 << gi;
+    if (deg < g) return cheb_node(cx, c, deg, gi - 1, target);
+    double *qc = (double *)calloc(g, sizeof(double)), *rc = (double *)calloc(g, sizeof(double));
+    cheb_split(c, deg, g, qc, rc);
+    int nq = cheb_node_nl(cx, qc, deg - g, gi - 1);
+    int lp = nq < cx->G[gi]->nl ? nq : cx->G[gi]->nl; /* limbs of the product before its rescale */
+    hy_ct *Q = cheb_node(cx, qc, deg - g, gi - 1, target * (double)p->q[lp - 1] / cx->G[gi]->scale);
     hy_ct *prod = hyo_mult(p, cx->k, Q, cx->G[gi]);
+    hy_ct *R = cheb_node(cx, rc, g - 1, gi - 1, prod->scale);
     int nl = prod->nl < R->nl ? prod->nl : R->nl;
     hyo_drop_to(p, prod, nl);
     hyo_drop_to(p, R, nl);
@@ -180,7 +214,7 @@ hy_ct *hyo_eval_chebyshev63(const hy_params *p, const hy_keys *k, const hy_ct *x
         }
     }
     cx.ng = gi + 1;
-    hy_ct *r = cheb_node(&cx, coeffs, degree, gi);
+    hy_ct *r = cheb_node(&cx, coeffs, degree, gi, p->delta);
     for (int j = 1; j <= 8; j++) hyo_ct_free(cx.T[j]);
     for (int i = 1; i < cx.ng; i++) hyo_ct_free(cx.G[i]);
     return r;
@@ -194,27 +228,36 @@ hy_ct *hyo_eval_f4(const hy_params *p, const hy_keys *k, const hy_ct *y) {
     hy_ct *y4 = hyo_mult(p, k, y2, y2);
     hy_ct *y8 = hyo_mult(p, k, y4, y4);
     int nl = y3->nl;
-    double S = p->delta * (double)p->q[nl - 1];
     hy_ct *yd = hyo_ct_clone(p, y);
     hyo_drop_to(p, yd, nl);
-    hy_ct *u = hyo_mul_const(p, yd, F4[1], S / yd->scale);
-    hy_ct *t = hyo_mul_const(p, y3, F4[3], S / y3->scale);
-    u->scale = t->scale = S;
-    hyo_add_inplace(p, u, t);
-    hyo_ct_free(t);
-    hyo_rescale_inplace(p, u);
+    /* v = c5 y + c7 y^3 at scale Delta; a = v y^4 fixes the scale every other summand is steered to */
+    double S = p->delta * (double)p->q[nl - 1];
     hy_ct *v = hyo_mul_const(p, yd, F4[5], S / yd->scale);
-    t = hyo_mul_const(p, y3, F4[7], S / y3->scale);
+    hy_ct *t = hyo_mul_const(p, y3, F4[7], S / y3->scale);
     v->scale = t->scale = S;
     hyo_add_inplace(p, v, t);
     hyo_ct_free(t);
     hyo_rescale_inplace(p, v);
+    v->scale = p->delta;
+    hy_ct *a = hyo_mult(p, k, v, y4);
+    /* u = c1 y + c3 y^3 at a's scale */
+    double Su = a->scale * (double)p->q[nl - 1];
+    hy_ct *u = hyo_mul_const(p, yd, F4[1], Su / yd->scale);
+    t = hyo_mul_const(p, y3, F4[3], Su / y3->scale);
+    u->scale = t->scale = Su;
+    hyo_add_inplace(p, u, t);
+    hyo_ct_free(t);
+    hyo_rescale_inplace(p, u);
+    u->scale = a->scale;
     hyo_ct_free(yd);
-    double S0 = p->delta * (double)p->q[y->nl - 1];
+    /* w = c9 y at the scale that makes b = w y^8 come out at a's scale */
+    int lb = (y->nl - 1) < y8->nl ? (y->nl - 1) : y8->nl;
+    double wt = a->scale * (double)p->q[lb - 1] / y8->scale;
+    double S0 = wt * (double)p->q[y->nl - 1];
     hy_ct *w = hyo_mul_const(p, y, F4[9], S0 / y->scale);
     w->scale = S0;
     hyo_rescale_inplace(p, w);
-    hy_ct *a = hyo_mult(p, k, v, y4);
+    w->scale = wt;
     hy_ct *b = hyo_mult(p, k, w, y8);
     int fl = a->nl < b->nl ? a->nl : b->nl;
     if (u->nl < fl) fl = u->nl;

@@ -228,3 +228,55 @@ def test_hers_reference_dataset_full_ring(im):
     assert receiver.decryptMembership(sender.membershipScenario(qc)) is True
     assert receiver.decryptIndex(sender.indexScenario(qc)) == [0]
     cc.close()
+
+
+def test_full_size_2p20_properties(im):
+    """BASELINE's headline size on one GPU (2^20 vectors, 64 blocks, 32768 database ciphertexts, 148 GiB resident) through
+    size-independent properties: (1) every one of the 2^20 decrypted scores within 1e-4 of plaintext cosine
+    (src/main_accuracy.cpp:359-360); (2) index = planted matches, membership true; (3) additivity in the query ciphertext:
+    similarity(qa + qb) decrypts to similarity(qa) + similarity(qb); (4) block independence (sender_diag.cpp:28-30): the score
+    ciphertext of block g out of the 64-block batched pass is BIT-identical to running that block alone in a second context
+    — which chains the batched full-size path to the single-block path that is bit-exact against the oracle."""
+    n = 1 << 20
+    cc = im.Context()
+    cc.keygen(21)
+    rng = np.random.default_rng(20250725)
+    db = rng.integers(-99, 100, size=(n, 512), dtype=np.int8).astype(np.float64)
+    planted = sorted([0, 12345, n // 2, n - 1])
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    qa = np.ones(512)
+    qb = rng.integers(-5, 6, size=512).astype(np.float64)
+    norms = np.linalg.norm(db, axis=1)
+    cos_a = (db @ (qa / np.linalg.norm(qa))) / norms
+    cos_b = (db @ (qb / np.linalg.norm(qb))) / norms
+    im.DiagonalEnroller(cc, n).serializeDB(db, seed=4)
+    del db
+    assert cc.db_stats()[1] == 32768
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    ca, cb = receiver.encryptQuery(qa, seed=5, nonce=1), receiver.encryptQuery(qb, seed=5, nonce=2)
+    sim_a = sender.computeSimilarity(ca)
+    assert len(sim_a) == 64
+    sa = cc.decrypt(sim_a).reshape(-1)
+    assert np.abs(sa - cos_a).max() < TOL
+    sb = cc.decrypt(sender.computeSimilarity(cb)).reshape(-1)
+    assert np.abs(sb - cos_b).max() < TOL
+    cab = cc.import_ct(ca.export(), ca.shape()[3])
+    cc.eval_add(cab, cb)  # in place (EvalAddInPlace)
+    sab = cc.decrypt(sender.computeSimilarity(cab)).reshape(-1)
+    assert np.abs(sab - (sa + sb)).max() < TOL
+    assert receiver.decryptIndex(sender.indexScenario(ca)) == planted
+    assert receiver.decryptMembership(sender.membershipScenario(ca)) is True
+    assert np.abs(cos_b).max() < 0.3 and receiver.decryptMembership(sender.membershipScenario(cb)) is False
+    # (4) one block alone, same ciphertexts, second context with the same keys
+    g = 37
+    sim_a_host = sim_a.export()
+    c2 = im.Context()
+    c2.keygen(21)
+    c2.db_alloc(16384)
+    for i in range(512):
+        c2.db_import_ct(i, cc.db_export_ct(g * 512 + i))
+    alone = im.DiagonalSender(c2, 16384).computeSimilarity(c2.import_ct(ca.export(), ca.shape()[3])).export()
+    assert np.array_equal(alone[0], sim_a_host[g])
+    c2.close()
+    cc.close()
