@@ -107,6 +107,24 @@ int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out) {
     return HYDIA_OK;
     API_END
 }
+int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const uint64_t *roots, uint32_t n_q, uint32_t n_p,
+                            int device, hydia_ctx **out) {
+    API_BEGIN
+    REQUIRE(p && out && moduli, "null argument");
+    REQUIRE(n_q >= 2 && n_p >= 1 && n_q + n_p <= HY_MAX_MODS, "bad limb counts");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
+    REQUIRE(device >= 0 && device < ndev, "bad device index");
+    Params prm = to_params(p);
+    prm.mult_depth = (int)n_q - 1;
+    prm.custom_q.assign(moduli, moduli + n_q + n_p);
+    if (roots) prm.custom_psi.assign(roots, roots + n_q + n_p);
+    prm.custom_nP = (int)n_p;
+    *out = new hydia_ctx(prm, device);
+    return HYDIA_OK;
+    API_END
+}
 void hydia_ctx_destroy(hydia_ctx *ctx) { delete ctx; }
 int hydia_get_info(const hydia_ctx *ctx, hydia_info *out) {
     REQUIRE(ctx && out, "null argument");

@@ -176,6 +176,20 @@ HostParams::HostParams(const Params &p) : prm(p) {
     delta = std::ldexp(1.0, p.scale_bits);
     const u64 M = 2ull * N;
 
+    if (!p.custom_q.empty()) {
+        // an externally generated chain (OpenFHE's, read through GetElementParams()): validate what the kernels rely on
+        nP = p.custom_nP;
+        nT = nQ + nP;
+        if (nP < 1 || (int)p.custom_q.size() != nT || nT > HY_MAX_MODS) throw std::runtime_error("hydia: custom moduli: need n_q + n_p primes");
+        if (!p.custom_psi.empty() && (int)p.custom_psi.size() != nT) throw std::runtime_error("hydia: custom roots: need n_q + n_p values");
+        q = p.custom_q;
+        for (int m = 0; m < nT; m++) {
+            if (q[m] % M != 1 || (q[m] >> 60) || !miller_rabin(q[m]))
+                throw std::runtime_error("hydia: custom modulus " + std::to_string(m) + " must be a prime < 2^60 that is 1 mod 2N");
+            for (int i = 0; i < m; i++)
+                if (q[i] == q[m]) throw std::runtime_error("hydia: custom moduli must be distinct");
+        }
+    } else {
     q.assign(nQ, 0);
     // scaling primes, assigned from the last limb down, alternating above / below 2^scale_bits
     u64 up = next_ntt_prime(1ull << p.scale_bits, M), dn = up;
@@ -196,11 +210,13 @@ HostParams::HostParams(const Params &p) : prm(p) {
     if (nT > HY_MAX_MODS) throw std::runtime_error("hydia: too many limbs");
     u64 pc = (p.first_bits == 60) ? q[0] : (1ull << 60);
     for (int k = 0; k < nP; k++) q.push_back(pc = prev_ntt_prime(pc, M));
+    }
 
     psi.resize(nT);
     mod.resize(nT);
     for (int m = 0; m < nT; m++) {
-        psi[m] = find_psi(q[m], M);
+        psi[m] = p.custom_psi.empty() ? find_psi(q[m], M) : p.custom_psi[m];
+        if (powmod_u64(psi[m], M / 2, q[m]) != q[m] - 1) throw std::runtime_error("hydia: root " + std::to_string(m) + " is not a primitive 2N-th root of unity");
         mod[m] = make_modc(q[m], N);
     }
     P_mod_q.resize(nQ);

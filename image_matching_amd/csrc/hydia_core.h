@@ -23,6 +23,10 @@ namespace hydia {
 
 struct Params {
     int logN = 15, mult_depth = 11, scale_bits = 45, first_bits = 60, dnum = 3, dim = 512;
+    // caller-supplied prime chain (hydia_ctx_create_custom): nQ ciphertext primes (q_0 first) then nP special primes;
+    // empty = derive.  custom_psi (optional) = the 2N-th roots of unity to use.
+    std::vector<u64> custom_q, custom_psi;
+    int custom_nP = 0;
 };
 
 // Caching HBM allocator: every evaluator temporary comes from here; all work is on ONE stream so a freed block

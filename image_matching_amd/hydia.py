@@ -59,6 +59,7 @@ def load_library():
         "hydia_params_describe": (i32, [C.POINTER(_Params), C.POINTER(_Info), vp, vp]),
         "hydia_compute_required_depth": (sz, [sz]),
         "hydia_ctx_create": (i32, [C.POINTER(_Params), i32, pp]),
+        "hydia_ctx_create_custom": (i32, [C.POINTER(_Params), vp, vp, u32, u32, i32, pp]),
         "hydia_ctx_destroy": (None, [vp]),
         "hydia_get_info": (i32, [vp, C.POINTER(_Info)]),
         "hydia_get_moduli": (i32, [vp, vp, vp]),
@@ -205,11 +206,19 @@ class Ciphertext:
 class Context:
     """CKKS context + keys + resident database on one GPU (replaces CryptoContext<DCRTPoly>, src/main.cpp:169-206)."""
 
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, moduli=None, roots=None, n_p=None):
+        """moduli (optional): a caller-supplied prime chain, n_q ciphertext primes then n_p special primes, with optional
+        2N-th roots — the OpenFHE-adapter path (hydia_ctx_create_custom)."""
         self.L = load_library()
         self.params = params or default_params()
         h = C.c_void_p()
-        _chk(self.L.hydia_ctx_create(C.byref(self.params), device, C.byref(h)))
+        if moduli is None:
+            _chk(self.L.hydia_ctx_create(C.byref(self.params), device, C.byref(h)))
+        else:
+            moduli = np.ascontiguousarray(moduli, dtype=np.uint64)
+            roots = None if roots is None else np.ascontiguousarray(roots, dtype=np.uint64)
+            _chk(self.L.hydia_ctx_create_custom(C.byref(self.params), _p(moduli), None if roots is None else _p(roots),
+                                                len(moduli) - n_p, n_p, device, C.byref(h)))
         self.h = h
         info = _Info()
         _chk(self.L.hydia_get_info(self.h, C.byref(info)))

@@ -67,6 +67,13 @@ size_t hydia_compute_required_depth(size_t approach);
 
 /* replaces GenCryptoContext + Enable(...) (src/main.cpp:169-179) for the sender/receiver on GPU `device` */
 int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out);
+/* Same, on a caller-supplied prime chain — the adapter path of SURVEY 8f-3: an OpenFHE context's ciphertext primes
+ * (cc->GetElementParams()->GetParams()[j]->GetModulus(), q_0 first) followed by its special primes
+ * (GetParamsP()), and optionally the 2N-th roots OpenFHE uses (GetRootOfUnity()) so evaluation-form data can cross the
+ * boundary unconverted.  n_q = mult_depth + 1.  Every modulus must be a distinct prime < 2^60 that is 1 mod 2N; limbs
+ * of at most 47 bits take the FP64 NTT path and limbs below 2^48 are stored as 48-bit residues in the database. */
+int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const uint64_t *roots /* may be NULL */,
+                            uint32_t n_q, uint32_t n_p, int device, hydia_ctx **out);
 void hydia_ctx_destroy(hydia_ctx *ctx);
 int hydia_get_info(const hydia_ctx *ctx, hydia_info *out);
 int hydia_get_moduli(const hydia_ctx *ctx, uint64_t *moduli, uint64_t *roots);

@@ -63,6 +63,39 @@ static u64 primitive_root_2n(u64 q, u64 m) {
     }
 }
 
+static void params_finish(hy_params *p, const u64 *roots);
+
+/* A context on a caller-supplied prime chain (an OpenFHE context's moduli read through GetElementParams()):
+ * moduli = nQ ciphertext primes (q_0 first) then nP special primes; roots (optional) = the 2N-th roots to use. */
+hy_params *hyo_params_create_custom(int logN, int nQ, int nP, int scale_bits, int dnum, int dim, const u64 *moduli,
+                                    const u64 *roots) {
+    if (nQ < 2 || nP < 1 || nQ + nP > HY_MAX_LIMBS) return NULL;
+    u64 M = 2ull << logN;
+    for (int m = 0; m < nQ + nP; m++) {
+        if (moduli[m] % M != 1 || (moduli[m] >> 60) || !is_prime_u64(moduli[m])) return NULL;
+        for (int i = 0; i < m; i++)
+            if (moduli[i] == moduli[m]) return NULL;
+        if (roots && (powmod(roots[m], M / 2, moduli[m]) != moduli[m] - 1)) return NULL;
+    }
+    hy_params *p = (hy_params *)calloc(1, sizeof(hy_params));
+    p->logN = logN;
+    p->N = 1 << logN;
+    p->slots = p->N / 2;
+    p->nQ = nQ;
+    p->nP = nP;
+    p->nT = nQ + nP;
+    p->dnum = dnum;
+    p->alpha = (nQ + dnum - 1) / dnum;
+    p->scale_bits = scale_bits;
+    p->first_bits = 0;
+    while ((moduli[0] >> p->first_bits) != 0) p->first_bits++;
+    p->dim = dim;
+    p->delta = ldexp(1.0, scale_bits);
+    for (int m = 0; m < p->nT; m++) p->q[m] = moduli[m];
+    params_finish(p, roots);
+    return p;
+}
+
 hy_params *hyo_params_create(int logN, int mult_depth, int scale_bits, int first_bits, int dnum, int dim) {
     hy_params *p = (hy_params *)calloc(1, sizeof(hy_params));
     p->logN = logN;
@@ -114,12 +147,18 @@ hy_params *hyo_params_create(int logN, int mult_depth, int scale_bits, int first
         p->q[p->nQ + k] = pc;
     }
     p->nT = p->nQ + p->nP;
+    params_finish(p, NULL);
+    return p;
+}
 
-    int N = p->N;
+/* everything derived from the prime chain */
+static void params_finish(hy_params *p, const u64 *roots) {
+    int N = p->N, logN = p->logN;
+    u64 M = 2ull * p->N;
     for (int m = 0; m < p->nT; m++) {
         u64 q = p->q[m];
         p->bq[m] = barrett_make(q);
-        p->psi[m] = primitive_root_2n(q, M);
+        p->psi[m] = roots ? roots[m] : primitive_root_2n(q, M);
         p->psi_inv[m] = invmod(p->psi[m], q);
         p->n_inv[m] = invmod((u64)N, q);
         p->n_inv_sh[m] = shoup_pre(p->n_inv[m], q);
@@ -182,7 +221,6 @@ hy_params *hyo_params_create(int logN, int mult_depth, int scale_bits, int first
         p->ksi_re[k] = cs;
         p->ksi_im[k] = sn;
     }
-    return p;
 }
 
 void hyo_params_free(hy_params *p) {

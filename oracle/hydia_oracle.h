@@ -77,6 +77,8 @@ typedef struct hy_keys {
 
 /* ---- params / primitives ---- */
 hy_params *hyo_params_create(int logN, int mult_depth, int scale_bits, int first_bits, int dnum, int dim);
+hy_params *hyo_params_create_custom(int logN, int nQ, int nP, int scale_bits, int dnum, int dim, const u64 *moduli,
+                                    const u64 *roots);
 void hyo_params_free(hy_params *p);
 void hyo_get_moduli(const hy_params *p, u64 *out);
 void hyo_get_roots(const hy_params *p, u64 *out);

@@ -34,6 +34,7 @@ def lib():
     vp = C.c_void_p
     sig = {
         "hyo_params_create": (vp, [C.c_int] * 6),
+        "hyo_params_create_custom": (vp, [C.c_int] * 6 + [vp, vp]),
         "hyo_params_free": (None, [vp]),
         "hyo_get_moduli": (None, [vp, vp]),
         "hyo_get_roots": (None, [vp, vp]),
@@ -125,9 +126,17 @@ def seed_bytes(x):
 
 
 class Params:
-    def __init__(self, log_n=15, depth=11, scale_bits=45, first_bits=60, dnum=3, dim=512):
+    def __init__(self, log_n=15, depth=11, scale_bits=45, first_bits=60, dnum=3, dim=512, moduli=None, roots=None, n_p=None):
         self.L = lib()
-        self.h = self.L.hyo_params_create(log_n, depth, scale_bits, first_bits, dnum, dim)
+        if moduli is None:
+            self.h = self.L.hyo_params_create(log_n, depth, scale_bits, first_bits, dnum, dim)
+        else:  # caller-supplied prime chain: n_q ciphertext primes (q_0 first) then n_p special primes
+            moduli = np.ascontiguousarray(moduli, dtype=np.uint64)
+            roots = None if roots is None else np.ascontiguousarray(roots, dtype=np.uint64)
+            self.h = self.L.hyo_params_create_custom(log_n, len(moduli) - n_p, n_p, scale_bits, dnum, dim, _ptr(moduli),
+                                                     None if roots is None else _ptr(roots))
+            if not self.h:
+                raise ValueError("oracle: custom moduli rejected")
         info = np.zeros(8, dtype=np.int32)
         self.L.hyo_get_info(self.h, _ptr(info))
         self.log_n, self.N, self.nQ, self.nP, self.dnum, self.alpha, self.dim, self.slots = [int(v) for v in info]
@@ -441,3 +450,34 @@ def read_dat(path):
     vals = np.array(tok[1:], dtype=np.float64)
     dim = (len(vals)) // (n + 1)
     return n, vals[:dim].copy(), vals[dim:].reshape(n, dim).copy()
+
+
+def alt_prime_chain(log_n, n_q=12, n_p=4, scale_bits=45, skip=25):
+    """A prime chain DIFFERENT from the derived one, with the shape OpenFHE produces for the reference's context (one ~60-bit
+    first prime, n_q-1 primes around 2^scale_bits, n_p ~60-bit special primes) — stands in for an externally generated
+    chain in the custom-context tests.  Returns (moduli, roots): roots are psi^3 of the smallest primitive 2N-th root, i.e.
+    also not the default choice."""
+    from sympy import isprime
+    M = 2 << log_n
+
+    def walk(start, step, count, skip_first):
+        out, c = [], start - (start % M) + 1
+        while len(out) < count + skip_first:
+            c += step * M
+            if isprime(c):
+                out.append(c)
+        return out[skip_first:]
+    scal = walk(1 << scale_bits, +1, (n_q - 1 + 1) // 2, skip) + walk(1 << scale_bits, -1, (n_q - 1) // 2, skip)
+    q = walk((1 << 59) + (1 << 58), -1, 1, 3) + scal[:n_q - 1]
+    p = walk(1 << 59, +1, n_p, 5)
+    moduli = q + p
+    roots = []
+    for m in moduli:
+        x = 2
+        while True:
+            r = pow(x, (m - 1) // M, m)
+            if pow(r, M // 2, m) == m - 1:
+                break
+            x += 1
+        roots.append(pow(r, 3, m))
+    return np.array(moduli, dtype=np.uint64), np.array(roots, dtype=np.uint64)

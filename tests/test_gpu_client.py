@@ -280,3 +280,23 @@ def test_full_size_2p20_properties(im):
     assert np.array_equal(alone[0], sim_a_host[g])
     c2.close()
     cc.close()
+
+
+def test_custom_chain_full_ring_end_to_end(im):
+    """The fast N = 2^15 kernels (FP64 / integer NTT paths chosen by modulus width, 48-bit packed database, fused passes) on
+    a caller-supplied prime chain with caller-supplied roots (hydia_ctx_create_custom): the reference's 2_10
+    data set still answers `true`, `[0]` with scores within 1e-4."""
+    moduli, roots = O.alt_prime_chain(15)
+    cc = im.Context(moduli=moduli, roots=roots, n_p=4)
+    assert np.array_equal(cc.moduli, moduli) and cc.db_stats is not None
+    cc.keygen(5)
+    g = np.load(os.path.join(GOLDEN, "dataset_2_10.npz"))
+    n, query, db = int(g["n"]), g["query"].astype(np.float64), g["db"].astype(np.float64)
+    im.DiagonalEnroller(cc, n).serializeDB(db, seed=9)
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    qc = receiver.encryptQuery(query, seed=5)
+    scores = cc.decrypt(sender.computeSimilarity(qc))[0]
+    assert np.abs(scores[:n] - g["cosine"]).max() < TOL and np.abs(scores[n:]).max() < TOL
+    assert receiver.decryptMembership(sender.membershipScenario(qc)) is True
+    assert receiver.decryptIndex(sender.indexScenario(qc)) == [0]
+    cc.close()

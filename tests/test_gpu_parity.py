@@ -211,3 +211,42 @@ def test_ntt15_pair_path_and_mixed_limbs(im):
         assert np.array_equal(f, np.stack([P.ntt_fwd(r, m) for r in a])), m
         assert np.array_equal(cc.ntt(f, m, inverse=True), a), m
     cc.close()
+
+
+def test_custom_prime_chain_context_bit_exact(im):
+    """hydia_ctx_create_custom: a context on a caller-supplied prime chain and 2N-th roots (what an OpenFHE
+    adapter passes in) runs the whole path bit-exact against the oracle configured with the same chain; malformed chains are
+    refused with HYDIA_ERR_ARG-class errors instead of computing garbage."""
+    moduli, roots = O.alt_prime_chain(11)
+    P = O.Params(log_n=11, depth=11, dim=64, moduli=moduli, roots=roots, n_p=4)
+    K = O.Keys(P, 3)
+    Or = O.Oracle(P, K)
+    cc = im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=moduli, roots=roots, n_p=4)
+    assert np.array_equal(cc.moduli, moduli) and np.array_equal(cc.roots, roots)
+    cc.keygen(3)
+    assert np.array_equal(cc.export_eval_key(0), K.relin())
+    rng = np.random.default_rng(5)
+    n = 1500
+    db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
+    db[13] = rng.integers(1, 4, size=P.dim)
+    query = np.ones(P.dim)
+    a, b = db.copy(), db.copy()
+    dbc = Or.enroll(a, 4)
+    im.DiagonalEnroller(cc, n).serializeDB(b, seed=4)
+    q = Or.encrypt_query(query, 6, 1)
+    gq = im.DiagonalReceiver(cc, n).encryptQuery(query, seed=6, nonce=1)
+    assert np.array_equal(gq.export()[0], q.data())
+    sender = im.DiagonalSender(cc, n)
+    sim, gsim = Or.compute_similarity(q, dbc, n), sender.computeSimilarity(gq).export()
+    idx, gidx = Or.index_scenario(q, dbc, n), sender.indexScenario(gq).export()
+    for g in range(len(sim)):
+        assert np.array_equal(gsim[g], sim[g].data()) and np.array_equal(gidx[g], idx[g].data())
+    mem = Or.membership_scenario(q, dbc, n)
+    assert np.array_equal(sender.membershipScenario(gq).export()[0], mem.data())
+    cc.close()
+    bad = moduli.copy()
+    bad[3] += 2
+    with pytest.raises(im.HydiaError):
+        im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=bad, n_p=4)
+    with pytest.raises(im.HydiaError):
+        im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=moduli, roots=moduli, n_p=4)

@@ -135,3 +135,33 @@ def test_hers_path_small_ring(small_params, small_keys, n, matches):
     P.L.hyo_hers_layout_row(P.h, dbn.ctypes.data, n, (G - 1) * P.dim + 3, slots.ctypes.data)
     k = min(n - (G - 1) * P.slots, P.slots) - 1
     assert slots[k] == dbn[(G - 1) * P.slots + k, 3] and (k + 1 == P.slots or slots[k + 1] == 0.0)
+
+
+def test_custom_prime_chain_context():
+    """hyo_params_create_custom (the OpenFHE-adapter path): the whole path on a caller-supplied prime chain and
+    caller-supplied 2N-th roots; bad chains are refused."""
+    moduli, roots = O.alt_prime_chain(11)
+    P = O.Params(log_n=11, depth=11, dim=64, moduli=moduli, roots=roots, n_p=4)
+    assert np.array_equal(P.moduli, moduli) and np.array_equal(P.roots, roots) and (P.nQ, P.nP) == (12, 4)
+    dflt = O.Params(log_n=11, depth=11, dim=64)
+    assert not set(int(v) for v in dflt.moduli) & set(int(v) for v in moduli)
+    K = O.Keys(P, 3)
+    Or = O.Oracle(P, K)
+    rng = np.random.default_rng(5)
+    n = 700
+    db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
+    db[13] = rng.integers(1, 4, size=P.dim)
+    query = np.ones(P.dim)
+    cos = (db / np.linalg.norm(db, axis=1, keepdims=True)) @ (query / np.linalg.norm(query))
+    dbc = Or.enroll(db.copy(), 4)
+    q = Or.encrypt_query(query, 6, 1)
+    sim = Or.compute_similarity(q, dbc, n)
+    scores = Or.decrypt(sim[0])
+    assert np.abs(scores[:n] - cos).max() < 1e-4
+    idx = Or.index_scenario(q, dbc, n)
+    found = Or.decrypt_index(idx)
+    assert 13 in found and all(cos[i] > 0.43 for i in found)
+    bad = moduli.copy()
+    bad[3] += 2
+    with pytest.raises(ValueError):
+        O.Params(log_n=11, depth=11, dim=64, moduli=bad, n_p=4)
