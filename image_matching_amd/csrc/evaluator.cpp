@@ -29,7 +29,7 @@ void Context::ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, co
 // ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
 // extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
 // NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.
-void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig) {
+void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own) {
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const size_t dig_x = (size_t)nd * nE * N;
     const LimbSel esel = sel_ext(nl);
@@ -85,7 +85,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
             if (lo > 0) ntt_fwd(out, dig_x, X, sel_range(0, lo));
             ntt_fwd(out + (size_t)hi * N, dig_x, X, rest);
         }
-        hk::copy_limbs(stream, N, c + (size_t)lo * N, out + (size_t)lo * N, c_outer, dig_x, X, sz);
+        if (copy_own) hk::copy_limbs(stream, N, c + (size_t)lo * N, out + (size_t)lo * N, c_outer, dig_x, X, sz);
     }
     pool.put(y);
 }
@@ -233,23 +233,28 @@ void Context::rescale(Ct &c, const Ct *sub, const double *addc) {
     pool.put(t);
     c = std::move(out);
 }
-void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc) {
+void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add) {
     if (c.npoly != 3) throw std::runtime_error("hydia: relin_rescale needs a 3-component ciphertext");
     const int nl = c.nl, l = nl - 1;
     if (prm.logN != 15 || !merge_rescale || l < 1 || l > HY_LC_LIMBS) {  // generic rings: the two steps in sequence
         relinearize(c, dbl);
-        rescale(c, sub, addc);
+        rescale(c, sub_is_add ? nullptr : sub, addc);
+        if (sub && sub_is_add) {
+            Ct sv = sub->alias(l);
+            add_inplace(c, sv);
+        }
         return;
     }
     if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
     if (sub && (sub->X != c.X || sub->npoly != 2 || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
-    modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
+    const u64 *c2 = c.d + 2 * c.poly_elems();
+    modup_digits(c2, c.ct_elems(), X, nl, dig, /*copy_own=*/false);  // the inner product reads a digit's own limbs from c2
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
     timer_begin("ks_inner_product");
-    hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel);
+    hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
     timer_end("ks_inner_product");
     pool.put(dig);
     // P limbs -> coefficient form (pre-multiplied by (P/p_k)^{-1})
@@ -292,6 +297,7 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc) 
     stp.dbl = dbl ? 1 : 0;
     stp.sub = sub ? sub->d : nullptr;
     stp.sub_ls = sub ? sub->lstride : 0;
+    stp.sub_add = sub_is_add ? 1 : 0;
     stp.has_addc = addc ? 1 : 0;
     stp.npoly = 2;
     if (addc)
@@ -462,6 +468,21 @@ Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
     cx->relin_rescale(o, true, nullptr, &minus_one);
     return o;
 }
+// a*b (relinearised, rescaled) + r with r already at the product's scale; r joins in the rescale epilogue when it has the limbs
+Ct mult_add(Context *cx, const Ct &a, const Ct &b, Ct &r) {
+    const int nl = std::min(a.nl, b.nl);
+    Ct x = a.alias(nl), y = b.alias(nl);
+    Ct o = cx->mult_norelin(x, y);
+    if (r.nl >= nl - 1) {
+        Ct rv = r.alias(nl - 1);
+        cx->relin_rescale(o, false, &rv, nullptr, true);
+    } else {
+        cx->relin_rescale(o);
+        cx->drop_to(o, r.nl);
+        cx->add_inplace(o, r);
+    }
+    return o;
+}
 int leaf_nl(Cheb &ch, const double *c, int deg) {
     int nl = ch.T[1].nl;
     for (int j = 1; j <= deg; j++)
@@ -524,13 +545,11 @@ Ct cheb_node(Cheb &ch, const double *c, int deg, int gi, double target) {
     const int nq = cheb_node_nl(ch, qc.data(), deg - g, gi - 1);
     const int lp = std::min(nq, ch.G[gi].nl);
     Ct Q = cheb_node(ch, qc.data(), deg - g, gi - 1, target * (double)cx->q[lp - 1] / ch.G[gi].scale);
-    Ct prod = cx->mult(Q, ch.G[gi]);
-    Ct R = cheb_node(ch, rc.data(), g - 1, gi - 1, prod.scale);
-    const int nl = std::min(prod.nl, R.nl);
-    cx->drop_to(prod, nl);
-    cx->drop_to(R, nl);
-    cx->add_inplace(prod, R);
-    return prod;
+    // the scale Q*T_g will have (same expression as mult): known before the product runs, so R is evaluated first and
+    // joins the product in the epilogue of its merged relinearise+rescale
+    const double prod_scale = (Q.scale * ch.G[gi].scale) / (double)cx->q[std::min(Q.nl, ch.G[gi].nl) - 1];
+    Ct R = cheb_node(ch, rc.data(), g - 1, gi - 1, prod_scale);
+    return mult_add(cx, Q, ch.G[gi], R);
 }
 // interpolation of step-at-delta at the degree+1 Chebyshev nodes (what EvalChebyshevFunction derives)
 std::vector<double> step_coeffs(double delta, int degree) {
@@ -586,26 +605,23 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     Ct y2 = mult(y, y), y3 = mult(y2, y), y4 = mult(y2, y2), y8 = mult(y4, y4);
     const int nl = y3.nl;
     Ct yd = y.alias(nl);
-    // v at scale Delta; a = v*y^4 fixes the scale the other two summands are steered to
+    // v at scale Delta; a = v*y^4 fixes the scale the other two summands are steered to.  u is evaluated before a and b
+    // and the sum a + b + u is formed in the rescale epilogues of the two products
     Ct v = lincomb({&yd, &y3}, {F4[5], F4[7]}, 0.0, delta * (double)q[nl - 1]);
     rescale(v);
     v.scale = delta;
-    Ct a = mult(v, y4);
-    Ct u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, a.scale * (double)q[nl - 1]);
+    const double a_scale = (v.scale * y4.scale) / (double)q[std::min(v.nl, y4.nl) - 1];
+    Ct u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, a_scale * (double)q[nl - 1]);
     rescale(u);
-    u.scale = a.scale;
+    u.scale = a_scale;
     const int lb = std::min(y.nl - 1, y8.nl);
-    const double wt = a.scale * (double)q[lb - 1] / y8.scale;
+    const double wt = a_scale * (double)q[lb - 1] / y8.scale;
     Ct w = lincomb({&y}, {F4[9]}, 0.0, wt * (double)q[y.nl - 1]);
     rescale(w);
     w.scale = wt;
-    Ct b = mult(w, y8);
-    const int fl = std::min(std::min(a.nl, b.nl), u.nl);
-    drop_to(a, fl);
-    drop_to(b, fl);
-    drop_to(u, fl);
-    add_inplace(a, b);
-    add_inplace(a, u);
+    Ct au = mult_add(this, v, y4, u);
+    Ct a = mult_add(this, w, y8, au);
+    a.scale = a_scale;
     add_const(a, 1.0);  // :182
     return a;
 }

@@ -148,7 +148,7 @@ struct Context : HostParams {
     void ntt_fwd(u64 *base, size_t outer, int X, const LimbSel &s);
     void ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc);
     // ModUp: c [X][nl][N] at stride c_outer -> dig [X][nd][nE][N]
-    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig);
+    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true);
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
     void ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
                   const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys, const unsigned *d_galois,
@@ -160,7 +160,7 @@ struct Context : HostParams {
     // RelinearizeInPlace followed by RescaleInPlace (sender_diag.cpp:79-80) as ONE pipeline with bit-identical results:
     // the dropped limb of the ModDown output is obtained in the coefficient domain, so ModDown's and Rescale's
     // corrections share a single forward NTT per remaining limb ((l+1) transforms per polynomial saved)
-    void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr);
+    void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
     bool merge_rescale = true;      // HYDIA_NO_MERGE_RESCALE: run the two steps separately (A/B)
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged

@@ -70,6 +70,7 @@ struct NttStore {
     int same_g;
     const u64 *sub;       // mode 2: - sub[xp*sub_ls*N + j*N + c]
     int sub_ls;
+    int sub_add;          // mode 3: the `sub` operand is ADDED instead (Paterson-Stockmeyer  Q*T_g + R)
     int has_addc;         // mode 2: + addc[j] on polynomials with xp % npoly == 0
     int npoly;
     u64 addc[HY_LC_LIMBS];
@@ -130,7 +131,8 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
 // acc[x][p][t][c] = sum_d dig[(x*dig_x_stride) + d][t][c] * key_x[d][p][mod(t)][c];  keys[x] -> [dnum][2][nT][N]
 // (same_key: every x uses keys[0])
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dig_x_stride, int nd,
-                   const u64 *const *keys, int same_key, int nT, u64 *acc, int X, const LimbSel &esel);
+                   const u64 *const *keys, int same_key, int nT, u64 *acc, int X, const LimbSel &esel,
+                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0);
 // out[x][p][j][c'] = ((acc[x][p][j][c] - conv[x][p][j][c]) * pinv[j] + (addend ? addend[x*add_x + p*add_ps + j*N + c] : 0)),
 // c = perm_g(c') when galois[x] != 1 (evaluation-form automorphism), acc rows have stride acc_limbs*N
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,

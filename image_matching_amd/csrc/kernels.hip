@@ -263,14 +263,18 @@ __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ m
 // grid (N/512, nE, X); 2 coefficients per thread, both key polys
 __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ mod, int N, const u64 *__restrict__ dig,
                                                        size_t dxs, int nd, const u64 *const *__restrict__ keys,
-                                                       int same_key, int nT, u64 *__restrict__ acc, LimbSel esel) {
+                                                       int same_key, int nT, u64 *__restrict__ acc, LimbSel esel,
+                                                       const u64 *__restrict__ own, size_t own_xs, int alpha, int nl) {
     const int t = blockIdx.y, x = blockIdx.z, nE = esel.n, m = esel.mod[t];
     const ModC M = mod[m];
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     const u64 *key = keys[same_key ? 0 : x];
     u128 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
     for (int d = 0; d < nd; d++) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(dig + (size_t)x * dxs + ((size_t)d * nE + t) * N + c);
+        // a digit's own limbs are the input itself (evaluation form): read them in place when the caller did not copy them
+        const u64 *src = (own && t < nl && t / alpha == d) ? own + (size_t)x * own_xs + (size_t)t * N + c
+                                                           : dig + (size_t)x * dxs + ((size_t)d * nE + t) * N + c;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
         const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 0) * nT + m) * N + c);
         const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 1) * nT + m) * N + c);
         a0x += (u128)v.x * kb.x;
@@ -603,9 +607,9 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
     hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
-                   int same_key, int nT, u64 *acc, int X, const LimbSel &esel) {
+                   int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl) {
     hipLaunchKernelGGL(k_inner_product, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
-                       nT, acc, esel);
+                       nT, acc, esel, own, own_xs, alpha, nl);
 }
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
                      const u64 *addend, size_t axs, size_t aps, int add_polys, u64 *out, int X, int nl,

@@ -304,7 +304,7 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
             if (pre.has_ex) t = addmod(t, ev[k], q);
             if (st.dbl) t = addmod(t, t, q);
             t = mulmod_shoup(submod(t, v[k], q), m2, m2s, q);
-            if (pre.has_sb) t = submod(t, sv[k], q);
+            if (pre.has_sb) t = st.sub_add ? addmod(t, sv[k], q) : submod(t, sv[k], q);
             if (st.has_addc && (xp % st.npoly) == 0) t = addmod(t, st.addc[j], q);
             r[k] = t;
         }
