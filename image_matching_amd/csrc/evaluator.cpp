@@ -368,6 +368,35 @@ Ct Context::lincomb(const std::vector<const Ct *> &terms, const std::vector<doub
     hk::lincomb(stream, d_mod, N, lc, o.d, f.X, f.npoly, f.nl);
     return o;
 }
+Ct Context::lincomb_multi(const std::vector<const Ct *> &terms, const std::vector<std::vector<double>> &coef,
+                          const std::vector<double> &c0, const std::vector<double> &S) {
+    const int K = (int)coef.size(), nt = (int)terms.size();
+    if (nt < 1 || nt > HY_LC_TERMS || K < 1 || (int)c0.size() != K || (int)S.size() != K) throw std::runtime_error("hydia: bad lincomb_multi");
+    const Ct &f = *terms[0];
+    if (f.nl > HY_LC_LIMBS) throw std::runtime_error("hydia: lincomb limb count");
+    LinCombMulti lc{};
+    lc.nterms = nt;
+    lc.K = K;
+    lcm_host.assign((size_t)K * HY_LCM_BLOCK, 0);
+    for (int t = 0; t < nt; t++) {
+        const Ct &a = *terms[t];
+        if (a.X != f.X || a.npoly != f.npoly || a.nl != f.nl) throw std::runtime_error("hydia: lincomb shape mismatch");
+        lc.src[t] = a.d;
+        lc.ls[t] = a.lstride;
+        for (int k = 0; k < K; k++)
+            for (int j = 0; j < f.nl; j++)
+                lcm_host[(size_t)k * HY_LCM_BLOCK + t * HY_LC_LIMBS + j] = double_to_mod(coef[k][t] * (S[k] / a.scale), q[j]);
+    }
+    for (int k = 0; k < K; k++)
+        for (int j = 0; j < f.nl; j++) lcm_host[(size_t)k * HY_LCM_BLOCK + HY_LC_TERMS * HY_LC_LIMBS + j] = double_to_mod(c0[k] * S[k], q[j]);
+    u64 *tab = pool.get(lcm_host.size() * sizeof(u64));
+    HIP_CHECK(hipMemcpyAsync(tab, lcm_host.data(), lcm_host.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
+    lc.tab = tab;
+    Ct o(this, f.X * K, f.npoly, f.nl, S[0]);
+    hk::lincomb_multi(stream, d_mod, N, lc, o.d, f.X, f.npoly, f.nl);
+    pool.put(tab);
+    return o;
+}
 // EvalMultNoRelin (sender_diag.cpp:93)
 Ct Context::mult_norelin(const Ct &a, const Ct &b) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
@@ -489,30 +518,6 @@ int leaf_nl(Cheb &ch, const double *c, int deg) {
         if (c[j] != 0.0) nl = std::min(nl, ch.T[j].nl);
     return nl;
 }
-// sum_j c_j T_j + c_0 in one fused pass, every constant encoded at target*q_l/scale(T_j): the rescaled leaf has scale `target`
-Ct cheb_leaf(Cheb &ch, const double *c, int deg, double target) {
-    Context *cx = ch.cx;
-    const int nl = leaf_nl(ch, c, deg);
-    bool any = false;
-    for (int j = 1; j <= deg; j++)
-        if (c[j] != 0.0) any = true;
-    const double S = target * (double)cx->q[nl - 1];
-    std::vector<Ct> views;
-    std::vector<double> coef;
-    const int last = any ? deg : 1;  // a pure constant is 0*T_1 + c_0
-    for (int j = 1; j <= last; j++) {
-        const double cj = any ? c[j] : 0.0;
-        if (cj == 0.0 && any) continue;
-        views.push_back(ch.T[j].alias(nl));
-        coef.push_back(cj);
-    }
-    std::vector<const Ct *> terms;
-    for (auto &v : views) terms.push_back(&v);
-    Ct acc = cx->lincomb(terms, coef, c[0], S);
-    cx->rescale(acc);
-    acc.scale = target;
-    return acc;
-}
 void cheb_split(const double *c, int deg, int g, std::vector<double> &qc, std::vector<double> &rc) {
     qc.assign(g, 0.0);
     rc.assign(c, c + g);
@@ -522,34 +527,121 @@ void cheb_split(const double *c, int deg, int g, std::vector<double> &qc, std::v
         rc[2 * g - j] -= c[j];
     }
 }
-int cheb_node_nl(Cheb &ch, const double *c, int deg, int gi) {  // limbs of cheb_node's result (dry run)
+int cheb_plan_nl(Cheb &ch, const double *c, int deg, int gi) {  // limbs a subtree's result will have
     while (deg > 0 && c[deg] == 0.0) deg--;
     if (deg < 8) return leaf_nl(ch, c, deg) - 1;
     const int g = 8 << gi;
-    if (deg < g) return cheb_node_nl(ch, c, deg, gi - 1);
+    if (deg < g) return cheb_plan_nl(ch, c, deg, gi - 1);
     std::vector<double> qc, rc;
     cheb_split(c, deg, g, qc, rc);
-    const int nq = cheb_node_nl(ch, qc.data(), deg - g, gi - 1), nr = cheb_node_nl(ch, rc.data(), g - 1, gi - 1);
+    const int nq = cheb_plan_nl(ch, qc.data(), deg - g, gi - 1), nr = cheb_plan_nl(ch, rc.data(), g - 1, gi - 1);
     return std::min(std::min(nq, ch.G[gi].nl) - 1, nr);
 }
-// sum_j c_j T_j at scale `target`; the target is pushed down the Paterson-Stockmeyer tree (quotient: target*q_l/scale(T_g),
-// remainder: the product's scale) so every addition joins operands of identical scale
-Ct cheb_node(Cheb &ch, const double *c, int deg, int gi, double target) {
+// The Paterson-Stockmeyer tree is PLANNED on the host first (scales and limb counts do not depend on ciphertext data), so
+// that all leaves over the same limbs run as ONE multi-output pass + ONE batched rescale; then the products are combined.
+// sum_j c_j T_j at scale `target`: the target is pushed down the tree (quotient: target*q_l/scale(T_g), remainder: the
+// product's scale) so every addition joins operands of identical scale.  A leaf encodes its constants at
+// target*q_l/scale(T_j): the rescaled leaf has scale `target` exactly.
+struct PNode {
+    bool leaf = false;
+    std::vector<double> c;  // leaf: c[0..deg]
+    int deg = 0, gi = 0, nl_in = 0, nl = 0, q = -1, r = -1, group = -1, slot = -1;
+    double target = 0, scale = 0;
+};
+int cheb_plan(Cheb &ch, std::vector<PNode> &tree, const double *c, int deg, int gi, double target) {
     Context *cx = ch.cx;
     while (deg > 0 && c[deg] == 0.0) deg--;
-    if (deg < 8) return cheb_leaf(ch, c, deg, target);
+    if (deg < 8) {
+        PNode n;
+        n.leaf = true;
+        n.c.assign(c, c + deg + 1);
+        n.deg = deg;
+        n.nl_in = leaf_nl(ch, c, deg);
+        n.nl = n.nl_in - 1;
+        n.target = n.scale = target;
+        tree.push_back(n);
+        return (int)tree.size() - 1;
+    }
     const int g = 8 << gi;
-    if (deg < g) return cheb_node(ch, c, deg, gi - 1, target);
+    if (deg < g) return cheb_plan(ch, tree, c, deg, gi - 1, target);
     std::vector<double> qc, rc;
     cheb_split(c, deg, g, qc, rc);
-    const int nq = cheb_node_nl(ch, qc.data(), deg - g, gi - 1);
-    const int lp = std::min(nq, ch.G[gi].nl);
-    Ct Q = cheb_node(ch, qc.data(), deg - g, gi - 1, target * (double)cx->q[lp - 1] / ch.G[gi].scale);
-    // the scale Q*T_g will have (same expression as mult): known before the product runs, so R is evaluated first and
-    // joins the product in the epilogue of its merged relinearise+rescale
-    const double prod_scale = (Q.scale * ch.G[gi].scale) / (double)cx->q[std::min(Q.nl, ch.G[gi].nl) - 1];
-    Ct R = cheb_node(ch, rc.data(), g - 1, gi - 1, prod_scale);
-    return mult_add(cx, Q, ch.G[gi], R);
+    const Ct &G = ch.G[gi];
+    const int nq = cheb_plan_nl(ch, qc.data(), deg - g, gi - 1);
+    const int lp = std::min(nq, G.nl);
+    PNode n;
+    n.gi = gi;
+    n.target = target;
+    n.q = cheb_plan(ch, tree, qc.data(), deg - g, gi - 1, target * (double)cx->q[lp - 1] / G.scale);
+    n.scale = (tree[n.q].scale * G.scale) / (double)cx->q[std::min(tree[n.q].nl, G.nl) - 1];  // what mult will report
+    n.r = cheb_plan(ch, tree, rc.data(), g - 1, gi - 1, n.scale);
+    n.nl = std::min(std::min(tree[n.q].nl, G.nl) - 1, tree[n.r].nl);
+    tree.push_back(n);
+    return (int)tree.size() - 1;
+}
+struct LeafGroup {
+    int nl_in = 0;
+    std::vector<int> nodes;
+    Ct out;  // [leaf][x]
+};
+Ct cheb_eval(Cheb &ch, std::vector<PNode> &tree, std::vector<LeafGroup> &groups, int id) {
+    Context *cx = ch.cx;
+    PNode &n = tree[id];
+    if (n.leaf) {
+        const Ct &big = groups[n.group].out;
+        const int X = ch.T[1].X;
+        Ct v = big.alias(big.nl);
+        v.X = X;
+        v.d = big.d + (size_t)n.slot * X * big.ct_elems();
+        v.scale = n.target;
+        return v;
+    }
+    Ct Q = cheb_eval(ch, tree, groups, n.q);
+    Ct R = cheb_eval(ch, tree, groups, n.r);
+    return mult_add(cx, Q, ch.G[n.gi], R);
+}
+Ct cheb_tree(Cheb &ch, const double *c, int degree, int gi, double target) {
+    Context *cx = ch.cx;
+    std::vector<PNode> tree;
+    const int root = cheb_plan(ch, tree, c, degree, gi, target);
+    std::vector<LeafGroup> groups;
+    for (int i = 0; i < (int)tree.size(); i++) {
+        if (!tree[i].leaf) continue;
+        int g = -1;
+        for (int k = 0; k < (int)groups.size(); k++)
+            if (groups[k].nl_in == tree[i].nl_in) g = k;
+        if (g < 0) {
+            groups.emplace_back();
+            g = (int)groups.size() - 1;
+            groups[g].nl_in = tree[i].nl_in;
+        }
+        tree[i].group = g;
+        tree[i].slot = (int)groups[g].nodes.size();
+        groups[g].nodes.push_back(i);
+    }
+    for (auto &grp : groups) {
+        int maxdeg = 1;  // a pure constant is 0*T_1 + c_0
+        for (int id : grp.nodes) maxdeg = std::max(maxdeg, tree[id].deg);
+        std::vector<Ct> views;
+        for (int j = 1; j <= maxdeg; j++) views.push_back(ch.T[j].alias(grp.nl_in));
+        std::vector<const Ct *> terms;
+        for (auto &v : views) terms.push_back(&v);
+        std::vector<std::vector<double>> coef;
+        std::vector<double> c0, S;
+        for (int id : grp.nodes) {
+            const PNode &n = tree[id];
+            std::vector<double> cj(maxdeg, 0.0);
+            for (int j = 1; j <= n.deg; j++) cj[j - 1] = n.c[j];
+            coef.push_back(cj);
+            c0.push_back(n.c[0]);
+            S.push_back(n.target * (double)cx->q[grp.nl_in - 1]);
+        }
+        grp.out = cx->lincomb_multi(terms, coef, c0, S);
+        cx->rescale(grp.out);
+    }
+    Ct res = cheb_eval(ch, tree, groups, root);
+    if (res.view) res = cx->clone(res);  // a tree that is a single leaf
+    return res;
 }
 // interpolation of step-at-delta at the degree+1 Chebyshev nodes (what EvalChebyshevFunction derives)
 std::vector<double> step_coeffs(double delta, int degree) {
@@ -598,7 +690,7 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
             gi++;
         }
     }
-    Ct y = cheb_node(ch, c.data(), degree, gi, delta);
+    Ct y = cheb_tree(ch, c.data(), degree, gi, delta);
     ch.G.clear();
     ch.T.clear();
     // f4 in depth 4: (c1 y + c3 y^3) + y^4 (c5 y + c7 y^3) + (c9 y) y^8   (openFHE_wrapper.cpp:158-169, :179)

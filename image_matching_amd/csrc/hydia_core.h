@@ -173,6 +173,10 @@ struct Context : HostParams {
     Ct mul_const(const Ct &a, double c, double const_scale);
     // sum_t coef[t] * terms[t] + c0 at common scale S (each constant encoded at S / scale(term)); all terms same X, npoly, nl
     Ct lincomb(const std::vector<const Ct *> &terms, const std::vector<double> &coef, double c0, double S);
+    // K leaves over the same terms in one pass: result batch [K][X] (leaf k = ciphertexts k*X .. k*X+X-1), every leaf at limb count of the terms
+    Ct lincomb_multi(const std::vector<const Ct *> &terms, const std::vector<std::vector<double>> &coef, const std::vector<double> &c0,
+                     const std::vector<double> &S);
+    std::vector<u64> lcm_host;  // staging of the constant table (kept alive across the asynchronous upload)
     Ct mult_norelin(const Ct &a, const Ct &b);
     Ct mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c);
     Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale

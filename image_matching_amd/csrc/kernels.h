@@ -44,6 +44,16 @@ struct LinComb {
     u64 c0[HY_LC_LIMBS];                   // constant added to polynomial 0
 };
 
+// K linear combinations of the SAME terms in one pass (the Paterson-Stockmeyer leaves share T_1..T_7): every term is read
+// once, K outputs are written.  tab (device): K blocks of [HY_LC_TERMS][HY_LC_LIMBS] constants followed by [HY_LC_LIMBS] c0.
+struct LinCombMulti {
+    int nterms, K;
+    const u64 *src[HY_LC_TERMS];
+    int ls[HY_LC_TERMS];
+    const u64 *tab;
+};
+#define HY_LCM_BLOCK (HY_LC_TERMS * HY_LC_LIMBS + HY_LC_LIMBS)
+
 // Fused prologue of the N = 2^15 forward NTT's first pass: where the coefficient-form input comes from
 struct NttLoad {
     int mode;             // 0 plain (src), 1 fast base conversion from `y`, 2 rescale spread from `y`
@@ -119,6 +129,8 @@ void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t src_oute
 // o[x][p][j] = sum_t src_t[x][p][j] * c[t][j] (+ c0[j] on p = 0): X cts of npoly polys, nl limbs, compact output
 void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl);
 // o[p][j] = sum_x in[x][p][j] mod q_j: EvalAdd chain over a batch (HERS sums its 512 per-dimension products); o compact
+// out[k][x][p][j][c] = sum_t tab[k][t][j] * src_t[x][p][j][c] (+ c0[k][j] on polynomial 0)
+void lincomb_multi(hipStream_t st, const ModC *mod, int N, const LinCombMulti &lc, u64 *o, int X, int npoly, int nl);
 void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl);
 // (a0 b0, a0 b1 + a1 b0, a1 b1) for X ciphertext pairs at nl limbs; o: [X][3][nl][N]
 void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls,

@@ -162,6 +162,38 @@ __global__ __launch_bounds__(256) void k_lincomb(const ModC *__restrict__ mod, i
     r.y = reduce64(ay, M);
     *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * nl * N + i) = r;
 }
+// grid (N/512, nl, X*npoly): the terms are loaded once into registers, then K outputs with wave-uniform constants
+// (128-bit lazy sums: 8 terms * 2^120 + c0 < 2^124)
+__global__ __launch_bounds__(256) void k_lincomb_multi(const ModC *__restrict__ mod, int N, LinCombMulti lc, u64 *__restrict__ o,
+                                                       int XP, int npoly, int nl) {
+    const int j = blockIdx.y, xp = blockIdx.z, p = xp % npoly;
+    const ModC M = mod[j];
+    const size_t i = (size_t)j * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    ulonglong2 v[HY_LC_TERMS];
+#pragma unroll
+    for (int t = 0; t < HY_LC_TERMS; t++)
+        v[t] = t < lc.nterms ? *reinterpret_cast<const ulonglong2 *>(lc.src[t] + (size_t)xp * lc.ls[t] * N + i) : make_ulonglong2(0, 0);
+    for (int k = 0; k < lc.K; k++) {
+        const u64 *tb = lc.tab + (size_t)k * HY_LCM_BLOCK;
+        u128 ax = 0, ay = 0;
+#pragma unroll
+        for (int t = 0; t < HY_LC_TERMS; t++)
+            if (t < lc.nterms) {
+                const u64 c = tb[t * HY_LC_LIMBS + j];
+                ax += (u128)v[t].x * c;
+                ay += (u128)v[t].y * c;
+            }
+        if (p == 0) {
+            const u64 c0 = tb[HY_LC_TERMS * HY_LC_LIMBS + j];
+            ax += c0;
+            ay += c0;
+        }
+        ulonglong2 r;
+        r.x = reduce128(ax, M);
+        r.y = reduce128(ay, M);
+        *reinterpret_cast<ulonglong2 *>(o + ((size_t)k * XP + xp) * nl * N + i) = r;
+    }
+}
 // grid (N/512, nl, npoly): serial sum over the batch with 128-bit accumulators (X * 2^60 fits)
 __global__ __launch_bounds__(256) void k_batch_sum(const ModC *__restrict__ mod, int N, const u64 *__restrict__ in,
                                                    u64 *__restrict__ o, int X, int npoly, int nl) {
@@ -583,6 +615,9 @@ void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, in
 }
 void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl) {
     hipLaunchKernelGGL(k_lincomb, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, npoly, nl);
+}
+void lincomb_multi(hipStream_t st, const ModC *mod, int N, const LinCombMulti &lc, u64 *o, int X, int npoly, int nl) {
+    hipLaunchKernelGGL(k_lincomb_multi, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, X * npoly, npoly, nl);
 }
 void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl) {
     hipLaunchKernelGGL(k_batch_sum, dim3(N / 512, nl, npoly), dim3(256), 0, st, mod, N, in, o, X, npoly, nl);
