@@ -325,6 +325,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
     fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
     merge_rescale = getenv("HYDIA_NO_MERGE_RESCALE") == nullptr;
+    fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)
         if (q[j] >> 48) db_packed = false;

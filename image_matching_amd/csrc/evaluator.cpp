@@ -29,7 +29,7 @@ void Context::ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, co
 // ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
 // extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
 // NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.
-void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own) {
+void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own, bool p1_only) {
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const size_t dig_x = (size_t)nd * nE * N;
     const LimbSel esel = sel_ext(nl);
@@ -82,8 +82,13 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
             }
         } else {
             hk::base_convert(stream, d_mod, N, y, (size_t)sz * N, out, dig_x, X, tab, esel);
-            if (lo > 0) ntt_fwd(out, dig_x, X, sel_range(0, lo));
-            ntt_fwd(out + (size_t)hi * N, dig_x, X, rest);
+            if (p1_only) {  // the caller runs the second pass fused with the inner product
+                if (lo > 0) hk::ntt15_forward_p1(stream, tabs, out, out, dig_x, dig_x, X, sel_range(0, lo));
+                if (rest.n > 0) hk::ntt15_forward_p1(stream, tabs, out + (size_t)hi * N, out + (size_t)hi * N, dig_x, dig_x, X, rest);
+            } else {
+                if (lo > 0) ntt_fwd(out, dig_x, X, sel_range(0, lo));
+                ntt_fwd(out + (size_t)hi * N, dig_x, X, rest);
+            }
         }
         if (copy_own) hk::copy_limbs(stream, N, c + (size_t)lo * N, out + (size_t)lo * N, c_outer, dig_x, X, sz);
     }
@@ -250,11 +255,17 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     const u64 *c2 = c.d + 2 * c.poly_elems();
-    modup_digits(c2, c.ct_elems(), X, nl, dig, /*copy_own=*/false);  // the inner product reads a digit's own limbs from c2
+    // the inner product reads a digit's own limbs from c2, and (fuse_ip) consumes the ModUp transforms' second pass directly
+    const bool fip = fuse_ip && !fuse_bconv;
+    modup_digits(c2, c.ct_elems(), X, nl, dig, /*copy_own=*/false, /*p1_only=*/fip);
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
     timer_begin("ks_inner_product");
-    hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
+    if (fip)
+        hk::ntt15_p2_inner_product(stream, tabs, d_mod, dig, (size_t)nd * nE * N, nd, X, nl, nP, nT, alpha, relin_key.d_cell, relin_key.d, c2,
+                                   c.ct_elems(), acc);
+    else
+        hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
     timer_end("ks_inner_product");
     pool.put(dig);
     // P limbs -> coefficient form (pre-multiplied by (P/p_k)^{-1})

@@ -148,7 +148,8 @@ struct Context : HostParams {
     void ntt_fwd(u64 *base, size_t outer, int X, const LimbSel &s);
     void ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc);
     // ModUp: c [X][nl][N] at stride c_outer -> dig [X][nd][nE][N]
-    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true);
+    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true, bool p1_only = false);
+    bool fuse_ip = true;  // relinearisation: second NTT pass of ModUp fused with the inner product (HYDIA_NO_FUSE_IP)
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
     void ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
                   const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys, const unsigned *d_galois,

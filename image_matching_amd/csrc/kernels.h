@@ -64,8 +64,18 @@ struct NttLoad {
     int t0;               // mode 1: target slot of sel slot 0 (tab column = t0 + slot)
 };
 // Fused epilogue of its second pass: what is done with the evaluation-form value v of limb j
+// store mode 4: the forward transform's results are consumed by the key-switching inner product instead of being stored —
+// a workgroup transforms limb t of EVERY digit that has to be extended to it, multiplies by the key and writes acc only
+struct IpArgs {
+    const u64 *key;   // [nd][2][nT][N]
+    int nT, nE, nl, alpha;
+    int own;          // 1: limbs t < nl also take their own digit's residues (evaluation form) from c2
+    const u64 *c2;    // [x][..][N] the polynomial being key-switched, limb t at c2 + x*c2_xs + t*N
+    size_t c2_xs;
+    u64 *acc;         // [x][2][nE][N]
+};
 struct NttStore {
-    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale
+    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale, 4 inner product
     u64 *out;             // modes 1,2: destination, compact [xp][nl][N]
     int nl;               // limbs of `out`
     const u64 *in;        // mode 1: acc [xp][in_ls][N] (Q limbs first); mode 2: ciphertext being rescaled [xp][in_ls][N]
@@ -84,6 +94,7 @@ struct NttStore {
     int has_addc;         // mode 2: + addc[j] on polynomials with xp % npoly == 0
     int npoly;
     u64 addc[HY_LC_LIMBS];
+    IpArgs ip;            // mode 4
 };
 
 
@@ -144,7 +155,12 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
 // (same_key: every x uses keys[0])
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dig_x_stride, int nd,
                    const u64 *const *keys, int same_key, int nT, u64 *acc, int X, const LimbSel &esel,
-                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0);
+                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0, int acc_rows = 0);
+// second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every
+// extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2)
+void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,
+                            int nl, int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc);
+void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel);
 // out[x][p][j][c'] = ((acc[x][p][j][c] - conv[x][p][j][c]) * pinv[j] + (addend ? addend[x*add_x + p*add_ps + j*N + c] : 0)),
 // c = perm_g(c') when galois[x] != 1 (evaluation-form automorphism), acc rows have stride acc_limbs*N
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,

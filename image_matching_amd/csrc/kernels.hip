@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ m
 __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ mod, int N, const u64 *__restrict__ dig,
                                                        size_t dxs, int nd, const u64 *const *__restrict__ keys,
                                                        int same_key, int nT, u64 *__restrict__ acc, LimbSel esel,
-                                                       const u64 *__restrict__ own, size_t own_xs, int alpha, int nl) {
-    const int t = blockIdx.y, x = blockIdx.z, nE = esel.n, m = esel.mod[t];
+                                                       const u64 *__restrict__ own, size_t own_xs, int alpha, int nl, int acc_rows) {
+    const int t = blockIdx.y, x = blockIdx.z, nE = acc_rows, m = esel.mod[t];
     const ModC M = mod[m];
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     const u64 *key = keys[same_key ? 0 : x];
@@ -642,9 +642,10 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
     hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
-                   int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl) {
+                   int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl,
+                   int acc_rows) {
     hipLaunchKernelGGL(k_inner_product, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
-                       nT, acc, esel, own, own_xs, alpha, nl);
+                       nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n);
 }
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
                      const u64 *addend, size_t axs, size_t aps, int add_polys, u64 *out, int X, int nl,

@@ -401,7 +401,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             }
         }
         P2Pre pre[2][NP];
-        if (ST != 0) {
+        if (ST != 0 && ST != 4) {
 #pragma unroll
             for (int hh = 0; hh < 2; hh++)
 #pragma unroll
@@ -414,6 +414,10 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             const int e = 4 * t + 1024 * hh, u = e & 255, la = (e >> 8) * LBLK + (u >> 5) * LROW + (u & 31);
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
+            // mode 4: lazy 128-bit sums of value * key over the digits this workgroup transforms (+ the limb's own digit)
+            u128 ipb[4] = {0, 0, 0, 0}, ipa[4] = {0, 0, 0, 0};
+            const int ip_t = slot, ip_m = ip_t < stp.ip.nl ? ip_t : stp.ip.nT - stp.ip.nE + ip_t;
+            const int ip_own = (stp.ip.own && ip_t < stp.ip.nl) ? ip_t / stp.ip.alpha : (1 << 30);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 T c0 = A::from_bits(lds[p][la]), c1 = A::from_bits(lds[p][la + 1]), c2 = A::from_bits(lds[p][la + 2]),
@@ -422,7 +426,16 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 ar.ct(c1, c3, W13);
                 ar.ct(c0, c1, W14a);
                 ar.ct(c2, c3, W14b);
-                if (ST == 0) {
+                if (ST == 4) {
+                    const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
+                    const int dgt = p >= ip_own ? p + 1 : p;
+                    const u64 *kb = stp.ip.key + (((size_t)dgt * 2) * stp.ip.nT + ip_m) * 32768 + (B0 + e);
+                    const u64 *ka = kb + (size_t)stp.ip.nT * 32768;
+                    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(kb), b1 = *reinterpret_cast<const ulonglong2 *>(kb + 2);
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ka), a1 = *reinterpret_cast<const ulonglong2 *>(ka + 2);
+                    ipb[0] += (u128)vv[0] * b0.x; ipb[1] += (u128)vv[1] * b0.y; ipb[2] += (u128)vv[2] * b1.x; ipb[3] += (u128)vv[3] * b1.y;
+                    ipa[0] += (u128)vv[0] * a0.x; ipa[1] += (u128)vv[1] * a0.y; ipa[2] += (u128)vv[2] * a1.x; ipa[3] += (u128)vv[3] * a1.y;
+                } else if (ST == 0) {
                     ulonglong2 o0, o1;
                     o0.x = ar.fin_fwd(c0); o0.y = ar.fin_fwd(c1);
                     o1.x = ar.fin_fwd(c2); o1.y = ar.fin_fwd(c3);
@@ -432,6 +445,25 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
                     p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[hh][p]);
                 }
+            }
+            if (ST == 4) {
+                const size_t ci = (size_t)(B0 + e);
+                if (ip_own < (1 << 30)) {
+                    const u64 *cv = stp.ip.c2 + (size_t)xp0 * stp.ip.c2_xs + (size_t)ip_t * 32768 + ci;
+                    const u64 *kb = stp.ip.key + (((size_t)ip_own * 2) * stp.ip.nT + ip_m) * 32768 + ci;
+                    const u64 *ka = kb + (size_t)stp.ip.nT * 32768;
+                    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(cv), v1 = *reinterpret_cast<const ulonglong2 *>(cv + 2);
+                    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(kb), b1 = *reinterpret_cast<const ulonglong2 *>(kb + 2);
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ka), a1 = *reinterpret_cast<const ulonglong2 *>(ka + 2);
+                    ipb[0] += (u128)v0.x * b0.x; ipb[1] += (u128)v0.y * b0.y; ipb[2] += (u128)v1.x * b1.x; ipb[3] += (u128)v1.y * b1.y;
+                    ipa[0] += (u128)v0.x * a0.x; ipa[1] += (u128)v0.y * a0.y; ipa[2] += (u128)v1.x * a1.x; ipa[3] += (u128)v1.y * a1.y;
+                }
+                u64 *ob = stp.ip.acc + (((size_t)xp0 * 2) * stp.ip.nE + ip_t) * 32768 + ci;
+                u64 *oa = ob + (size_t)stp.ip.nE * 32768;
+                *reinterpret_cast<ulonglong2 *>(ob) = make_ulonglong2(reduce128(ipb[0], M), reduce128(ipb[1], M));
+                *reinterpret_cast<ulonglong2 *>(ob + 2) = make_ulonglong2(reduce128(ipb[2], M), reduce128(ipb[3], M));
+                *reinterpret_cast<ulonglong2 *>(oa) = make_ulonglong2(reduce128(ipa[0], M), reduce128(ipa[1], M));
+                *reinterpret_cast<ulonglong2 *>(oa + 2) = make_ulonglong2(reduce128(ipa[2], M), reduce128(ipa[3], M));
             }
         }
     } else {
@@ -536,9 +568,68 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
     else p2_body<IntA, INV, NP, ST>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
 }
 
+// second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
+// workgroups that share a key tile follow each other.  Limb t = t0 + slot; the NP digits are all digits but the limb's own.
+template <int NP, bool OWN>
+__global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
+    constexpr int N = 32768;
+    __shared__ u64 lds[NP][8 * 288];
+    const int y = blockIdx.y, slot = y / X, x = y - slot * X, t = t0 + slot;
+    const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
+    const ModC M = T.mod[m];
+    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
+    const int B0 = blockIdx.x * 2048;
+    const int own_d = OWN ? t / stp.ip.alpha : (1 << 30);
+    const u64 *s[NP];
+    u64 *d[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int dgt = p >= own_d ? p + 1 : p;
+        s[p] = dig + (size_t)x * dxs + ((size_t)dgt * stp.ip.nE + t) * N + B0;
+        d[p] = nullptr;
+    }
+    if (fp) p2_body<FpA, false, NP, 4>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+    else p2_body<IntA, false, NP, 4>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+}
+
 }  // namespace
 
 namespace hk {
+
+void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dxs, int nd, int X, int nl,
+                            int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc) {
+    const int nE = nl + nP;
+    NttStore stp{};
+    stp.mode = 4;
+    stp.ip.key = key;
+    stp.ip.nT = nT;
+    stp.ip.nE = nE;
+    stp.ip.nl = nl;
+    stp.ip.alpha = alpha;
+    stp.ip.own = 1;
+    stp.ip.c2 = c2;
+    stp.ip.c2_xs = c2_xs;
+    stp.ip.acc = acc;
+    // Q limbs: nd - 1 digits are transformed, the limb's own digit is read from c2
+    if (nd == 1) {
+        LimbSel qs{};
+        qs.n = nl;
+        for (int j = 0; j < nl; j++) qs.mod[j] = j;
+        inner_product(st, mod, 32768, dig, dxs, nd, keys, 1, nT, acc, X, qs, c2, c2_xs, alpha, nl, nE);
+    } else if (nd == 2) {
+        hipLaunchKernelGGL((k_ntt15_p2_ip<1, true>), dim3(16, nl * X), dim3(256), 0, st, T, dig, dxs, X, 0, stp);
+    } else if (nd == 3) {
+        hipLaunchKernelGGL((k_ntt15_p2_ip<2, true>), dim3(16, nl * X), dim3(256), 0, st, T, dig, dxs, X, 0, stp);
+    } else {
+        hipLaunchKernelGGL((k_ntt15_p2_ip<3, true>), dim3(16, nl * X), dim3(256), 0, st, T, dig, dxs, X, 0, stp);
+    }
+    // P limbs: every digit is transformed
+    if (nd == 1) hipLaunchKernelGGL((k_ntt15_p2_ip<1, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+    else if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip<2, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+    else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip<3, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+    else hipLaunchKernelGGL((k_ntt15_p2_ip<4, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+}
 
 template <int LD>
 static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
@@ -566,6 +657,10 @@ void ntt15_forward(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
     NttStore stp{};
     launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
     launch_p2_fwd<0>(st, T, dst, dso, X, sel, stp);
+}
+void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel) {
+    NttLoad ld{};
+    launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
 }
 void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                          const LimbSel &sel, const NttLoad &ld, const NttStore &stp) {
