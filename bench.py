@@ -211,10 +211,14 @@ def main():
                                      "computeSimilarity_vectors_per_s_per_gpu": round(n / ms_similarity * 1e3)}},
             "roofline": {"kernel": "k_hydia_tensor", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches": int(launches),
                          "note": "algorithmic bytes = SURVEY 8d figure (196608 B per DB vector at 8 B per residue) + rotated queries + "
-                                 "accumulators; one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two kernels)"},
+                                 "accumulators; one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two kernels); traffic = PMC "
+                                 "HBM bytes per launch (profiles/tensor_traffic.json), below the algorithmic bytes because the database's "
+                                 "45/46-bit limbs are resident as 48-bit residues; traffic_rate = traffic / launch time in GB/s, to be read "
+                                 "against the guide's measured 6.29 TB/s copy ceiling"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
