@@ -286,9 +286,12 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     tab.ns = nP;
     tab.nt = nl;
     for (int k = 0; k < nP; k++)
-        for (int j = 0; j < nl; j++) tab.f[k][j] = Phat_mod_q[k][j];
+        for (int j = 0; j < nl; j++) {  // P^{-1} and the doubling folded into the conversion constants
+            u64 f = mulmod_u64(Phat_mod_q[k][j], Pinv_mod_q[j], q[j]);
+            tab.f[k][j] = dbl ? (f + f) % q[j] : f;
+        }
     u64 *w = pool.get((size_t)XP * l * N * sizeof(u64));
-    hk::moddown_rescale_conv(stream, d_mod, N, y, u, w, XP, l, nP, tab, pinv_sel, dbl ? 1 : 0);
+    hk::moddown_rescale_conv(stream, d_mod, N, y, u, w, XP, l, nP, tab);
     const LimbSel qsel = sel_q(l);
     Ct out(this, X, 2, l, c.scale / (double)q[l]);
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);

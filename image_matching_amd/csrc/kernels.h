@@ -172,7 +172,7 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
 // y  [xp][nP][N]  : INTT of acc's P limbs times (P/p_k)^{-1}
 // w  [xp][l][N]   : (conv_j P^{-1})(x2) + centred(y_l) mod q_j, whose NTT is subtracted in the pass-2 epilogue (mode 3)
 void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
-                          const ConvTab &tab, const ScaleSel &pinv, int dbl);
+                          const ConvTab &tab /* f[s][j] = (P/p_s) P^{-1} (x2) mod q_j, j <= l */);
 // u[xp][c] = (acc[xp][l][c] * pinv_l + addend[x*add_x + p*add_p + l*N + c])(x2)   (evaluation form, limb l)
 void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
                        size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl);

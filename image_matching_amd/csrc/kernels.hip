@@ -346,10 +346,12 @@ __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict_
     if (addend && p < add_polys) v = addmod(v, addend[(size_t)x * axs + (size_t)p * aps + (size_t)j * N + c], q);
     out[((size_t)xp * nl + j) * N + co] = v;
 }
-// grid (N/512, XP): see moddown_rescale_conv in kernels.h.  Two coefficients per thread.
+// grid (N/512, XP): see moddown_rescale_conv in kernels.h.  Two coefficients per thread.  The conversion constants arrive with
+// P^{-1} (and the doubling) already folded in: tab.f[s][j] = (P/p_s mod q_j) * P^{-1} (* 2) mod q_j, so a target costs nP lazy
+// multiply-accumulates and ONE reduction.
 __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
                                                               const u64 *__restrict__ u, u64 *__restrict__ w, int l, int nP,
-                                                              ConvTab tab, ScaleSel pinv, int dbl) {
+                                                              ConvTab tab) {
     const int xp = blockIdx.y;
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     ulonglong2 v[HY_MAX_DIGIT];
@@ -365,15 +367,11 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
             ax += (u128)v[s].x * tab.f[s][l];
             ay += (u128)v[s].y * tab.f[s][l];
         }
-    u64 mx = mulmod_shoup(reduce128(ax, Ml), pinv.s[l], pinv.s_sh[l], Ml.q);
-    u64 my = mulmod_shoup(reduce128(ay, Ml), pinv.s[l], pinv.s_sh[l], Ml.q);
-    if (dbl) {
-        mx = addmod(mx, mx, Ml.q);
-        my = addmod(my, my, Ml.q);
-    }
     const ulonglong2 uu = *reinterpret_cast<const ulonglong2 *>(u + (size_t)xp * N + c);
-    const u64 ylx = submod(uu.x, mx, Ml.q), yly = submod(uu.y, my, Ml.q);
+    const u64 ylx = submod(uu.x, reduce128(ax, Ml), Ml.q), yly = submod(uu.y, reduce128(ay, Ml), Ml.q);
     const u64 half = Ml.q >> 1;
+    const bool negx = ylx > half, negy = yly > half;
+    const u64 magx = negx ? Ml.q - ylx : ylx, magy = negy ? Ml.q - yly : yly;  // |centred residue|
     for (int j = 0; j < l; j++) {
         const ModC M = mod[j];
         u128 bx = 0, by = 0;
@@ -383,17 +381,10 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
                 bx += (u128)v[s].x * tab.f[s][j];
                 by += (u128)v[s].y * tab.f[s][j];
             }
-        u64 wx = mulmod_shoup(reduce128(bx, M), pinv.s[j], pinv.s_sh[j], M.q);
-        u64 wy = mulmod_shoup(reduce128(by, M), pinv.s[j], pinv.s_sh[j], M.q);
-        if (dbl) {
-            wx = addmod(wx, wx, M.q);
-            wy = addmod(wy, wy, M.q);
-        }
-        const u64 rx = ylx > half ? negmod(reduce64(Ml.q - ylx, M), M.q) : reduce64(ylx, M);
-        const u64 ry = yly > half ? negmod(reduce64(Ml.q - yly, M), M.q) : reduce64(yly, M);
+        const u64 rx = reduce64(magx, M), ry = reduce64(magy, M);
         ulonglong2 o;
-        o.x = addmod(wx, rx, M.q);
-        o.y = addmod(wy, ry, M.q);
+        o.x = addmod(reduce128(bx, M), negx ? negmod(rx, M.q) : rx, M.q);
+        o.y = addmod(reduce128(by, M), negy ? negmod(ry, M.q) : ry, M.q);
         *reinterpret_cast<ulonglong2 *>(w + ((size_t)xp * l + j) * N + c) = o;
     }
 }
@@ -654,8 +645,8 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
                        conv, addend, axs, aps, add_polys, out, nl, pinv, galois, same_g);
 }
 void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
-                          const ConvTab &tab, const ScaleSel &pinv, int dbl) {
-    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab, pinv, dbl);
+                          const ConvTab &tab) {
+    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab);
 }
 void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
                        size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl) {
