@@ -391,7 +391,12 @@ Ct Context::lincomb_multi(const std::vector<const Ct *> &terms, const std::vecto
     LinCombMulti lc{};
     lc.nterms = nt;
     lc.K = K;
-    lcm_host.assign((size_t)K * HY_LCM_BLOCK, 0);
+    if (lcm_stage.size() >= 64) {  // uploads are asynchronous: recycle the staging buffers only behind a stream fence
+        HIP_CHECK(hipStreamSynchronize(stream));
+        lcm_stage.clear();
+    }
+    lcm_stage.emplace_back((size_t)K * HY_LCM_BLOCK, 0);
+    std::vector<u64> &lcm_host = lcm_stage.back();
     for (int t = 0; t < nt; t++) {
         const Ct &a = *terms[t];
         if (a.X != f.X || a.npoly != f.npoly || a.nl != f.nl) throw std::runtime_error("hydia: lincomb shape mismatch");

@@ -177,7 +177,7 @@ struct Context : HostParams {
     // K leaves over the same terms in one pass: result batch [K][X] (leaf k = ciphertexts k*X .. k*X+X-1), every leaf at limb count of the terms
     Ct lincomb_multi(const std::vector<const Ct *> &terms, const std::vector<std::vector<double>> &coef, const std::vector<double> &c0,
                      const std::vector<double> &S);
-    std::vector<u64> lcm_host;  // staging of the constant table (kept alive across the asynchronous upload)
+    std::vector<std::vector<u64>> lcm_stage;  // host staging of the constant tables: kept alive until the stream has consumed them
     Ct mult_norelin(const Ct &a, const Ct &b);
     Ct mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c);
     Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale
