@@ -84,7 +84,10 @@ def main():
     # HYDIA_BENCH_REHEARSE=1: every rank computes on GPU 0 and the gather goes through gloo/host memory — lets the multi-rank
     # control flow be exercised on a one-GPU box (never used for reported numbers)
     rehearse = os.environ.get("HYDIA_BENCH_REHEARSE") == "1"
-    if world > 1:
+    # HYDIA_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1): take the multi-rank path with a one-rank RCCL group — exercises
+    # the real nccl init / gather / device-pointer plumbing on a one-GPU box
+    multi = world > 1 or os.environ.get("HYDIA_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch  # noqa: F811  (device memory + RCCL only)
         import torch.distributed as dist  # noqa: F811
         if rehearse:
@@ -118,7 +121,7 @@ def main():
 
     def step():
         res = sender.indexScenario(qc)
-        if world > 1:
+        if multi:
             nonlocal gather_buf, gather_list
             cnt, npoly, nl, _ = res.shape()
             if rehearse:
@@ -134,14 +137,14 @@ def main():
 
     def fence():
         cc.sync()
-        if world > 1:
+        if multi:
             if not rehearse:
                 torch.cuda.synchronize()
             dist.barrier()
             if not rehearse:
                 torch.cuda.synchronize()
 
-    if world > 1 and not rehearse:
+    if multi and not rehearse:
         # open the RCCL send/recv channels of the gather outside the timed region even when --warmup 0 (lazy connection
         # set-up takes seconds; it is communicator start-up, not part of a query)
         probe = torch.zeros(1024, dtype=torch.int64, device="cuda")
@@ -156,7 +159,7 @@ def main():
         res = step()
     fence()
     elapsed = time.time() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -174,7 +177,7 @@ def main():
     correct = True
     if not args.random_db:
         correct = receiver.decryptIndex(res) == planted
-        if world > 1 and rank == 0:
+        if multi and rank == 0:
             cnt, npoly, nl, scale = res.shape()
             for r in range(1, world):
                 if rehearse:
@@ -229,7 +232,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     cc.close()
