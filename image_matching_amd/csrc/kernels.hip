@@ -8,6 +8,8 @@
 //   k_moddown_combine     ModDown's (acc - conv) / P, + c0, + the evaluation-form automorphism of EvalFastRotation
 //   k_hydia_tensor        512 x EvalMultNoRelin + 511 x EvalAddInPlace per block (sender_diag.cpp:70-77, :93)
 //   k_rescale_*           RescaleInPlace (sender_diag.cpp:80)
+//   k_tensor, k_lincomb*  ct x ct products and Chebyshev/f4 leaves of chebyshevCompare (src/openFHE_wrapper.cpp:143-185)
+//   k_batch_sum           HERS: sum of the per-dimension products (src/sender/sender_hers.cpp:60-87)
 // No MFMA: this is 64-bit integer modular arithmetic.  HBM-streaming kernels read 16 B per lane (1 KiB per wave
 // instruction) of one limb, so modulus constants are wave-uniform.
 #include "kernels.h"

@@ -1,4 +1,4 @@
-// include/hydia_roles.hpp — the reference's C++ role surface for approach 5, over the C-ABI of hydia.h.
+// include/hydia_roles.hpp — the reference's C++ role surface for approach 5 (HyDia) and approach 4 (HERS), over the C-ABI of hydia.h.
 //
 // Same class and method names as /root/reference/include/{sender,sender_diag,receiver,receiver_hers,receiver_diag,
 // enroller_diag}.h so that src/main.cpp's case 5 (:245-247, :324-327, :333-374) reads unchanged; the OpenFHE handle
@@ -115,7 +115,7 @@ class Sender {
     CryptoContext cc;
     size_t numVectors;
 };
-// ---- include/sender_diag.h:5-28 (HersSender's own bodies are approach 4, out of scope)
+// ---- include/sender_diag.h:5-28 (HersSender, approach 4, is further down)
 class DiagonalSender : public Sender {
   public:
     DiagonalSender(CryptoContext ccParam, size_t vectorParam) : Sender(std::move(ccParam), vectorParam) {}
