@@ -105,13 +105,14 @@ u64 double_to_mod(double v, u64 q) {
 Pool::~Pool() { trim(); }
 u64 *Pool::get(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
-    auto it = free_.lower_bound(bytes);
+    auto &fl = free_[cur];
+    auto it = fl.lower_bound(bytes);
     u64 *p;
-    if (it != free_.end() && it->first <= bytes + bytes / 4 + 4096) {
+    if (it != fl.end() && it->first <= bytes + bytes / 4 + 4096) {
         p = it->second;
         bytes_cached -= it->first;
         bytes = it->first;
-        free_.erase(it);
+        fl.erase(it);
     } else {
         hipError_t e = hipMalloc((void **)&p, bytes);
         if (e != hipSuccess) {
@@ -119,7 +120,7 @@ u64 *Pool::get(size_t bytes) {
             HIP_CHECK(hipMalloc((void **)&p, bytes));
         }
     }
-    size_[p] = bytes;
+    size_[p] = {bytes, cur};
     bytes_live += bytes;
     peak = std::max(peak, bytes_live + bytes_cached);
     return p;
@@ -128,13 +129,14 @@ void Pool::put(u64 *p) {
     if (!p) return;
     auto it = size_.find(p);
     if (it == size_.end()) return;
-    free_.emplace(it->second, p);
-    bytes_live -= it->second;
-    bytes_cached += it->second;
+    free_[it->second.second].emplace(it->second.first, p);  // back to the lane that owns it
+    bytes_live -= it->second.first;
+    bytes_cached += it->second.first;
     size_.erase(it);
 }
 void Pool::trim() {
-    for (auto &kv : free_) (void)hipFree(kv.second);
+    for (auto &fl : free_)
+        for (auto &kv : fl.second) (void)hipFree(kv.second);
     free_.clear();
     bytes_cached = 0;
 }
@@ -270,6 +272,13 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     // ---- device side
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    lane_stream.push_back(stream);
+    if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
+    for (int k = 1; k < nlanes; k++) {
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        lane_stream.push_back(st);
+    }
     size_t tb = (size_t)nT * N * sizeof(u64);
     std::vector<u64> tw((size_t)nT * N), tws((size_t)nT * N), itw((size_t)nT * N), itws((size_t)nT * N);
     for (int m = 0; m < nT; m++) {
@@ -337,7 +346,8 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
 
 Context::~Context() {
     (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto st : lane_stream) (void)hipStreamSynchronize(st);
+    stream = lane_stream.empty() ? stream : lane_stream[0];
     for (auto &kv : timers)
         for (auto &ev : kv.second.pending) {
             (void)hipEventDestroy(ev.first);
@@ -352,7 +362,16 @@ Context::~Context() {
                     (void *)d_rotptrs,
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
+    for (auto e : lane_ev) (void)hipEventDestroy(e);
+    for (size_t k = 1; k < lane_stream.size(); k++) (void)hipStreamDestroy(lane_stream[k]);
     if (stream) (void)hipStreamDestroy(stream);
+}
+void Context::set_lane(int k) {
+    stream = lane_stream[k];
+    pool.cur = k;
+}
+void Context::sync_all() {
+    for (auto st : lane_stream) HIP_CHECK(hipStreamSynchronize(st));
 }
 
 LimbSel Context::sel_q(int nl) const { return sel_range(0, nl); }

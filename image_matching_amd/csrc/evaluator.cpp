@@ -392,7 +392,7 @@ Ct Context::lincomb_multi(const std::vector<const Ct *> &terms, const std::vecto
     lc.nterms = nt;
     lc.K = K;
     if (lcm_stage.size() >= 64) {  // uploads are asynchronous: recycle the staging buffers only behind a stream fence
-        HIP_CHECK(hipStreamSynchronize(stream));
+        sync_all();
         lcm_stage.clear();
     }
     lcm_stage.emplace_back((size_t)K * HY_LCM_BLOCK, 0);
@@ -479,15 +479,7 @@ Ct Context::rotate_query(const Ct &qc) {
 }
 // computeSimilarity (sender_diag.cpp:12-33): all G blocks of the resident DB in one tensor-accumulate launch
 Ct Context::similarity(const Ct &qc) {
-    if (!d_db || db_cts == 0 || db_kind != 5) throw std::runtime_error("hydia: no database resident (diagonal packing)");
-    if (qc.nl != nQ) throw std::runtime_error("hydia: query must be a fresh (level 0) ciphertext");
-    const int dim = prm.dim;
-    const int G = (int)(db_cts / dim);
-    Ct rot = rotate_query(qc);
-    Ct acc(this, G, 3, nQ, qc.scale * delta);
-    timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
-    timer_end("hydia_tensor");
+    Ct acc = similarity_accumulate(qc);
     relin_rescale(acc);
     return acc;
 }
@@ -737,10 +729,65 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     return a;
 }
 
-// indexScenario (sender_diag.cpp:52-63): one comparator pass over the batch of all G score ciphertexts
+// relinearise + rescale + compare of a degree-2 batch, split over the comparator LANES: each lane runs the whole chain on its
+// share of the blocks on its own stream, so the latency- and multiplier-bound kernels of one lane fill the HBM idle time of
+// another's (loop B itself stays alone on the main stream).  Same arithmetic per ciphertext whatever the split.
+Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
+    const int G = acc.X, L = std::min(nlanes, G);
+    if (L <= 1) {
+        relin_rescale(acc);
+        return chebyshev_compare(acc, dlt, sign_depth);
+    }
+    while ((int)lane_ev.size() < nlanes + 1) {  // created once, re-recorded per call
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        lane_ev.push_back(e);
+    }
+    std::vector<hipEvent_t> &ev = lane_ev;
+    HIP_CHECK(hipEventRecord(ev[L], stream));  // acc is ready (everything enqueued on the main stream so far)
+    std::vector<Ct> res(L);
+    Ct out;
+    for (int k = 0; k < L; k++) {
+        const int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
+        set_lane(k);
+        if (k > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev[L], 0));
+        Ct part = acc.alias(acc.nl);
+        part.X = g1 - g0;
+        part.d = acc.d + (size_t)g0 * acc.ct_elems();
+        relin_rescale(part);
+        res[k] = chebyshev_compare(part, dlt, sign_depth);
+        if (k == 0) {
+            out = Ct(this, G, res[0].npoly, res[0].nl, res[0].scale);
+            HIP_CHECK(hipEventRecord(ev[0], stream));  // `out` may recycle main-lane memory: other lanes write it only after this
+        } else {
+            HIP_CHECK(hipStreamWaitEvent(stream, ev[0], 0));
+        }
+        Ct rk = res[k].compact() ? res[k].alias(res[k].nl) : clone(res[k]);
+        HIP_CHECK(hipMemcpyAsync(out.d + (size_t)g0 * out.ct_elems(), rk.d, rk.bytes(), hipMemcpyDeviceToDevice, stream));
+        if (k > 0) HIP_CHECK(hipEventRecord(ev[k], stream));
+    }
+    set_lane(0);
+    for (int k = 1; k < L; k++) HIP_CHECK(hipStreamWaitEvent(stream, ev[k], 0));  // main stream: results complete, acc released
+    res.clear();  // each lane's buffers return to that lane's free list (Pool::put)
+    return out;
+}
+// the degree-2 accumulators of loop B for all resident blocks (computeSimilarity without its relinearise / rescale tail)
+Ct Context::similarity_accumulate(const Ct &qc) {
+    if (!d_db || db_cts == 0 || db_kind != 5) throw std::runtime_error("hydia: no database resident (diagonal packing)");
+    if (qc.nl != nQ) throw std::runtime_error("hydia: query must be a fresh (level 0) ciphertext");
+    const int dim = prm.dim;
+    const int G = (int)(db_cts / dim);
+    Ct rot = rotate_query(qc);
+    Ct acc(this, G, 3, nQ, qc.scale * delta);
+    timer_begin("hydia_tensor");
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
+    timer_end("hydia_tensor");
+    return acc;
+}
+// indexScenario (sender_diag.cpp:52-63): loop A, loop B, then the per-block tails on the comparator lanes
 Ct Context::index_scenario(const Ct &qc) {
-    Ct s = similarity(qc);
-    return chebyshev_compare(s, 0.44 /* MATCH_THRESHOLD, include/config.h:9 */, 10 /* COMP_DEPTH, :14 */);
+    Ct acc = similarity_accumulate(qc);
+    return relin_compare_lanes(acc, 0.44 /* MATCH_THRESHOLD, include/config.h:9 */, 10 /* COMP_DEPTH, :14 */);
 }
 // membershipScenario (sender_diag.cpp:35-50): EvalAddManyInPlace over blocks, then EvalSum over all slots
 Ct Context::membership_scenario(const Ct &qc) {

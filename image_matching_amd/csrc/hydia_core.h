@@ -29,8 +29,9 @@ struct Params {
     int custom_nP = 0;
 };
 
-// Caching HBM allocator: every evaluator temporary comes from here; all work is on ONE stream so a freed block
-// can be handed to the next request without synchronisation.
+// Caching HBM allocator: every evaluator temporary comes from here.  Work is enqueued on one stream per LANE; a block is
+// cached on the free list of the lane that allocated it and only handed out again on that lane, so reuse is ordered by the
+// lane's stream without synchronisation.  `cur` selects the lane new requests are served from (Context::set_lane).
 class Pool {
   public:
     ~Pool();
@@ -38,10 +39,11 @@ class Pool {
     void put(u64 *p);
     void trim();
     size_t bytes_live = 0, bytes_cached = 0, peak = 0;
+    int cur = 0;
 
   private:
-    std::multimap<size_t, u64 *> free_;
-    std::map<u64 *, size_t> size_;
+    std::map<int, std::multimap<size_t, u64 *>> free_;    // per lane
+    std::map<u64 *, std::pair<size_t, int>> size_;         // block -> (bytes, owning lane)
 };
 
 struct Context;
@@ -91,7 +93,12 @@ struct HostParams {
 
 struct Context : HostParams {
     int device;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // the CURRENT lane's stream (lane 0 unless inside a multi-lane section)
+    std::vector<hipStream_t> lane_stream;  // lane 0 = the main stream
+    int nlanes = 2;                        // comparator lanes (HYDIA_LANES)
+    std::vector<hipEvent_t> lane_ev;
+    void set_lane(int k);
+    void sync_all();
     Pool pool;
 
     // device tables
@@ -179,6 +186,8 @@ struct Context : HostParams {
                      const std::vector<double> &S);
     std::vector<std::vector<u64>> lcm_stage;  // host staging of the constant tables: kept alive until the stream has consumed them
     Ct mult_norelin(const Ct &a, const Ct &b);
+    Ct similarity_accumulate(const Ct &qc);
+    Ct relin_compare_lanes(Ct &acc, double delta, int sign_depth);
     Ct mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c);
     Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale
     Ct rotate(const Ct &a, int rot);    // X = any; full key switch
