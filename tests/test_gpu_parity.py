@@ -250,3 +250,38 @@ def test_custom_prime_chain_context_bit_exact(im):
         im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=bad, n_p=4)
     with pytest.raises(im.HydiaError):
         im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=moduli, roots=moduli, n_p=4)
+
+
+def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
+    """Every fast-path decision at N = 2^15 is bit-neutral: the default engine (FP64 NTT butterflies on the 45-bit limbs, 48-bit
+    packed database, merged ModDown+Rescale, NTT pass 2 fused with the inner product, two comparator lanes) and the plain one
+    (integer butterflies everywhere, 8-byte database, separate relinearise / rescale, unfused inner product, one lane) give
+    identical residues for a 3-block database (batched X = 3 evaluator ops, uneven lane split) — index, membership and scores."""
+    variants = [
+        {},
+        {"HYDIA_NTT_INT": "1", "HYDIA_DB_UNPACKED": "1", "HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "1"},
+        {"HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "3"},
+    ]
+    n = 40000
+    rng = np.random.default_rng(77)
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
+    for i in (5, 20000, n - 1):
+        db[i] = rng.integers(1, 4, size=512)
+    results = []
+    for env in variants:
+        for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cc = im.Context()
+        cc.keygen(31)
+        im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=8)
+        sender = im.DiagonalSender(cc, n)
+        q = im.DiagonalReceiver(cc, n).encryptQuery(np.ones(512), seed=2, nonce=9)
+        results.append((sender.computeSimilarity(q).export(), sender.indexScenario(q).export(), sender.membershipScenario(q).export()))
+        if not env:
+            assert im.DiagonalReceiver(cc, n).decryptIndex(sender.indexScenario(q)) == [5, 20000, n - 1]
+        cc.close()
+    for r in results[1:]:
+        for a, b in zip(results[0], r):
+            assert np.array_equal(a, b)
