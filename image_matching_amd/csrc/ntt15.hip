@@ -61,7 +61,10 @@ struct FpA {
     double q, qinv;
     DEV FpA(const ModC &M) : q((double)M.q), qinv(1.0 / (double)M.q) {}
     DEV static TW tw(const ulonglong2 b) { return make_double2(__longlong_as_double((long long)b.x), __longlong_as_double((long long)b.y)); }
-    DEV T from_canon(u64 x) const { return (double)(long long)x; }  // x < 2^47: exact
+    // integer <-> double without the emulated 64-bit conversions: for 0 <= x < 2^52 the bit pattern 0x433.. | x IS the double 2^52 + x
+    DEV static double u2d(u64 x) { return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0; }
+    DEV static u64 d2u(double r) { return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull; }  // r integral in [0, 2^52)
+    DEV T from_canon(u64 x) const { return u2d(x); }  // x < 2^47: exact
     DEV static T from_bits(u64 x) { return __longlong_as_double((long long)x); }
     DEV static u64 to_bits(T x) { return (u64)__double_as_longlong(x); }
     DEV double mulmod(const double v, const TW W) const {  // exact v*w - c*q with |result| <= 0.75 q
@@ -84,13 +87,13 @@ struct FpA {
     DEV u64 fin_fwd(T x) const {
         recentre(x);
         if (x < 0) x += q;
-        return (u64)(long long)x;
+        return d2u(x);
     }
     DEV u64 fin_inv(T x, u64 sc, u64) const {
-        const double s = (double)(long long)sc;
+        const double s = u2d(sc);
         double r = mulmod(x, make_double2(s, s * qinv));
         if (r < 0) r += q;
-        return (u64)(long long)r;
+        return d2u(r);
     }
 };
 
