@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void k_lincomb_multi(const ModC *__restrict__ 
             ay += c0;
         }
         ulonglong2 r;
-        r.x = reduce128(ax, M);
-        r.y = reduce128(ay, M);
+        r.x = reduce_lazy(ax, M, lc.nterms + 1);
+        r.y = reduce_lazy(ay, M, lc.nterms + 1);
         *reinterpret_cast<ulonglong2 *>(o + ((size_t)k * XP + xp) * nl * N + i) = r;
     }
 }
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, in
     ulonglong2 d0, d1, d2;
     d0.x = mulmod(a0.x, b0.x, M);
     d0.y = mulmod(a0.y, b0.y, M);
-    d1.x = reduce128((u128)a0.x * b1.x + (u128)a1.x * b0.x, M);
-    d1.y = reduce128((u128)a0.y * b1.y + (u128)a1.y * b0.y, M);
+    d1.x = reduce128k((u128)a0.x * b1.x + (u128)a1.x * b0.x, M);
+    d1.y = reduce128k((u128)a0.y * b1.y + (u128)a1.y * b0.y, M);
     d2.x = mulmod(a1.x, b1.x, M);
     d2.y = mulmod(a1.y, b1.y, M);
     if (SUB) {
@@ -288,9 +288,10 @@ __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ m
                 ax += (u128)v[s].x * tab.f[s][t];
                 ay += (u128)v[s].y * tab.f[s][t];
             }
+        // sources are residues of OTHER moduli (< 2^60), constants < q_t: up to four terms stay below 2^(k+62)
         ulonglong2 r;
-        r.x = reduce128(ax, M);
-        r.y = reduce128(ay, M);
+        r.x = tab.ns <= 4 ? reduce128k(ax, M) : reduce128(ax, M);
+        r.y = tab.ns <= 4 ? reduce128k(ay, M) : reduce128(ay, M);
         *reinterpret_cast<ulonglong2 *>(out + (size_t)x * oo + (size_t)t * N + c) = r;
     }
 }
@@ -317,10 +318,10 @@ __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ 
         a1y += (u128)v.y * ka.y;
     }
     ulonglong2 r0, r1;
-    r0.x = reduce128(a0x, M);
-    r0.y = reduce128(a0y, M);
-    r1.x = reduce128(a1x, M);
-    r1.y = reduce128(a1y, M);
+    r0.x = reduce_lazy(a0x, M, nd);
+    r0.y = reduce_lazy(a0y, M, nd);
+    r1.x = reduce_lazy(a1x, M, nd);
+    r1.y = reduce_lazy(a1y, M, nd);
     *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 0) * nE + t) * N + c) = r0;
     *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 1) * nE + t) * N + c) = r1;
 }
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict_
     if (addend && p < add_polys) v = addmod(v, addend[(size_t)x * axs + (size_t)p * aps + (size_t)j * N + c], q);
     out[((size_t)xp * nl + j) * N + co] = v;
 }
-// grid (N/512, XP): see moddown_rescale_conv in kernels.h.  Two coefficients per thread.  The conversion constants arrive with
+// grid (N/512, XP): see moddown_rescale_conv in kernels.h.  Two coefficients per thread.  (Sources are P-limb residues < 2^60:
+// up to four terms stay below 2^(k+62), the range of reduce128k.)  The conversion constants arrive with
 // P^{-1} (and the doubling) already folded in: tab.f[s][j] = (P/p_s mod q_j) * P^{-1} (* 2) mod q_j, so a target costs nP lazy
 // multiply-accumulates and ONE reduction.
 __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
             ay += (u128)v[s].y * tab.f[s][l];
         }
     const ulonglong2 uu = *reinterpret_cast<const ulonglong2 *>(u + (size_t)xp * N + c);
-    const u64 ylx = submod(uu.x, reduce128(ax, Ml), Ml.q), yly = submod(uu.y, reduce128(ay, Ml), Ml.q);
+    const u64 ylx = submod(uu.x, (nP <= 4 ? reduce128k(ax, Ml) : reduce128(ax, Ml)), Ml.q), yly = submod(uu.y, (nP <= 4 ? reduce128k(ay, Ml) : reduce128(ay, Ml)), Ml.q);
     const u64 half = Ml.q >> 1;
     const bool negx = ylx > half, negy = yly > half;
     const u64 magx = negx ? Ml.q - ylx : ylx, magy = negy ? Ml.q - yly : yly;  // |centred residue|
@@ -385,8 +387,8 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
             }
         const u64 rx = reduce64(magx, M), ry = reduce64(magy, M);
         ulonglong2 o;
-        o.x = addmod(reduce128(bx, M), negx ? negmod(rx, M.q) : rx, M.q);
-        o.y = addmod(reduce128(by, M), negy ? negmod(ry, M.q) : ry, M.q);
+        o.x = addmod((nP <= 4 ? reduce128k(bx, M) : reduce128(bx, M)), negx ? negmod(rx, M.q) : rx, M.q);
+        o.y = addmod((nP <= 4 ? reduce128k(by, M) : reduce128(by, M)), negy ? negmod(ry, M.q) : ry, M.q);
         *reinterpret_cast<ulonglong2 *>(w + ((size_t)xp * l + j) * N + c) = o;
     }
 }

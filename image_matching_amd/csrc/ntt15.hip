@@ -463,10 +463,10 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 }
                 u64 *ob = stp.ip.acc + (((size_t)xp0 * 2) * stp.ip.nE + ip_t) * 32768 + ci;
                 u64 *oa = ob + (size_t)stp.ip.nE * 32768;
-                *reinterpret_cast<ulonglong2 *>(ob) = make_ulonglong2(reduce128(ipb[0], M), reduce128(ipb[1], M));
-                *reinterpret_cast<ulonglong2 *>(ob + 2) = make_ulonglong2(reduce128(ipb[2], M), reduce128(ipb[3], M));
-                *reinterpret_cast<ulonglong2 *>(oa) = make_ulonglong2(reduce128(ipa[0], M), reduce128(ipa[1], M));
-                *reinterpret_cast<ulonglong2 *>(oa + 2) = make_ulonglong2(reduce128(ipa[2], M), reduce128(ipa[3], M));
+                *reinterpret_cast<ulonglong2 *>(ob) = make_ulonglong2(reduce_lazy(ipb[0], M, NP + 1), reduce_lazy(ipb[1], M, NP + 1));
+                *reinterpret_cast<ulonglong2 *>(ob + 2) = make_ulonglong2(reduce_lazy(ipb[2], M, NP + 1), reduce_lazy(ipb[3], M, NP + 1));
+                *reinterpret_cast<ulonglong2 *>(oa) = make_ulonglong2(reduce_lazy(ipa[0], M, NP + 1), reduce_lazy(ipa[1], M, NP + 1));
+                *reinterpret_cast<ulonglong2 *>(oa + 2) = make_ulonglong2(reduce_lazy(ipa[2], M, NP + 1), reduce_lazy(ipa[3], M, NP + 1));
             }
         }
     } else {
