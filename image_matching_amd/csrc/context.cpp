@@ -453,6 +453,7 @@ void Context::db_fetch(size_t t0, u64 *d_plain, int X) {
 // ------------------------------------------------------------------ kernel timers
 void Context::timer_begin(const char *name) {
     if (!timing) return;
+    if (timers[name].pending.size() >= 2048) timer_collect();  // bound the event backlog of a caller that never reads the timers
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a));
     HIP_CHECK(hipEventCreate(&b));
