@@ -161,6 +161,23 @@ def test_error_behaviour(im, small):
     assert e.value.code == -2
     with pytest.raises(im.HydiaError):
         fresh.import_ct(np.zeros((1, 5, 2, P.N), dtype=np.uint64), 1.0)
+    # empty database (the reference prints an error and returns, enroller_diag.cpp:17-28): refused, nothing becomes resident
+    with pytest.raises(im.HydiaError) as e:
+        im.DiagonalEnroller(cc, 0).serializeDB(np.zeros((0, P.dim)), seed=1)
+    assert e.value.code == -1
+    # a database beyond the HBM of the device: a clean device error, and the context stays usable
+    with pytest.raises(im.HydiaError) as e:
+        fresh.db_alloc(1 << 29)
+    assert e.value.code == -3
+    fresh.keygen(7)
+    db = np.ones((3, P.dim))
+    im.DiagonalEnroller(fresh, 3).serializeDB(db, seed=2)
+    fq = im.DiagonalReceiver(fresh, 3).encryptQuery(np.ones(P.dim), seed=3)
+    assert im.DiagonalReceiver(fresh, 3).decryptIndex(im.DiagonalSender(fresh, 3).indexScenario(fq)) == [0, 1, 2]
+    # a query that is not at level 0 is refused (sender_diag.cpp multiplies fresh ciphertexts only)
+    low = fresh.import_ct(fq.export()[:, :, :5], fq.shape()[3])
+    with pytest.raises(im.HydiaError):
+        im.DiagonalSender(fresh, 3).computeSimilarity(low)
     fresh.close()
 
 
