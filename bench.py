@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20, help="log2 of DB vectors PER GPU (default 2^20 = 192 GiB of ciphertexts)")
+    ap.add_argument("--total-log2n", type=int, default=None,
+                    help="strong-scaling variant (BASELINE configs 4/5): log2 of the TOTAL DB vectors, split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-db", action="store_true", help="fill the DB with random residues instead of enrolling")
     args = ap.parse_args()
@@ -98,7 +100,8 @@ def main():
 
     import image_matching_amd as im
     cc = im.Context(im.default_params(), 0 if rehearse else local_rank)
-    n = 1 << args.log2n
+    strong = args.total_log2n is not None
+    n = (1 << args.total_log2n) // world if strong else 1 << args.log2n
     dim, S = cc.dim, cc.slots
     G = -(-n // S)
 
@@ -196,7 +199,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("log2n") == args.log2n:
+                if tj.get("log2n") == args.log2n and not strong:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -206,11 +209,11 @@ def main():
             "unit": "vectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB per GPU (%d blocks of 16384, "
                                    "%.0f GiB of ciphertexts resident in HBM), one query per step through indexScenario"
-                                   % (args.log2n, G, G * dim * 2 * cc.nQ * cc.N * 8 / 2 ** 30),
+                                   % (n.bit_length() - 1, G, G * dim * 2 * cc.nQ * cc.N * 8 / 2 ** 30),
                        "db_vectors_total": world * n, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3", "sharding": "row-block per GPU, RCCL gather of results",
                        "db_storage": "%.1f GiB resident (45/46-bit limbs held as 48-bit residues)" % (cc.db_stats()[2] / 2 ** 30),
