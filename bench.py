@@ -22,6 +22,11 @@ import time
 
 import numpy as np
 
+# The engine runs two comparator lanes (HIP streams); torch and RCCL bring their own.  With ROCm's default of 4 hardware queues
+# the lanes end up sharing a queue with RCCL's streams and serialise (+4 ms per query, measured with tools/probe_dist.py), so ask
+# for 8 before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -4,6 +4,12 @@ The product is libhydia.so (hand-written gfx950 HIP kernels + C++ host, C-ABI in
 the thin Python host mirror of the reference's role classes over that C-ABI; it never computes on the CPU and
 raises if the HIP library is missing.
 """
+import os as _os
+
+# two comparator lanes + whatever streams the host application (torch, RCCL) creates: more than ROCm's default 4 hardware
+# queues, or the lanes share a queue and serialise.  Only effective if set before the HIP runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .hydia import (Context, Ciphertext, DiagonalEnroller, DiagonalReceiver, DiagonalSender, HydiaError,  # noqa: F401
                     HersEnroller, HersReceiver, HersSender,
                     default_params, describe_params, compute_required_depth, lib_path, load_library)
