@@ -744,6 +744,10 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
         lane_ev.push_back(e);
     }
     std::vector<hipEvent_t> &ev = lane_ev;
+    struct LaneGuard {  // an exception inside a lane (out of memory, ...) must not leave the context pointing at a side lane
+        Context *c;
+        ~LaneGuard() { c->set_lane(0); }
+    } guard{this};
     HIP_CHECK(hipEventRecord(ev[L], stream));  // acc is ready (everything enqueued on the main stream so far)
     std::vector<Ct> res(L);
     Ct out;
