@@ -13,6 +13,8 @@
 
 #include "hydia_core.h"
 
+#include <exception>
+
 namespace hydia {
 
 static u64 shoup_h(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
@@ -746,7 +748,11 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
     std::vector<hipEvent_t> &ev = lane_ev;
     struct LaneGuard {  // an exception inside a lane (out of memory, ...) must not leave the context pointing at a side lane
         Context *c;
-        ~LaneGuard() { c->set_lane(0); }
+        ~LaneGuard() {
+            c->set_lane(0);
+            if (std::uncaught_exceptions() > 0)  // error path: let every lane drain before buffers shared across lanes are released
+                for (auto st : c->lane_stream) (void)hipStreamSynchronize(st);
+        }
     } guard{this};
     HIP_CHECK(hipEventRecord(ev[L], stream));  // acc is ready (everything enqueued on the main stream so far)
     std::vector<Ct> res(L);
