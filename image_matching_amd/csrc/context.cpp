@@ -335,6 +335,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
     merge_rescale = getenv("HYDIA_NO_MERGE_RESCALE") == nullptr;
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
+    rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)
         if (q[j] >> 48) db_packed = false;
@@ -359,7 +360,7 @@ Context::~Context() {
         for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
             if (p) (void)hipFree(p);
     for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp, (void *)d_twf, (void *)d_itwf,
-                    (void *)d_rotptrs,
+                    (void *)d_rotptrs, (void *)d_rotpack,
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     for (auto e : lane_ev) (void)hipEventDestroy(e);

@@ -101,12 +101,12 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
 // automorphism (EvalFastRotation's tail).  out: [X][2][nl][N].
 void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
                        const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys,
-                       const unsigned *d_galois, const unsigned *d_ginv, int same_galois, bool dbl, u64 *out) {
+                       const unsigned *d_galois, const unsigned *d_ginv, int same_galois, bool dbl, u64 *out, int keys_packed_nQ) {
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
     timer_begin("ks_inner_product");
-    hk::inner_product(stream, d_mod, N, dig, dig_x_stride, nd, d_keys, same_key, nT, acc, X, esel);
+    hk::inner_product(stream, d_mod, N, dig, dig_x_stride, nd, d_keys, same_key, nT, acc, X, esel, nullptr, 0, 1, 0, 0, keys_packed_nQ);
     timer_end("ks_inner_product");
     // P limbs -> coefficient form, pre-multiplied by (P/p_k)^{-1}
     LimbSel psel = sel_range(nQ, nT);
@@ -165,15 +165,36 @@ void Context::build_rotptrs() {
     if (rotptrs_valid) return;
     std::vector<const u64 *> ptrs(prm.dim, nullptr);
     std::vector<unsigned> gal(prm.dim, 1u), ginv(prm.dim, 1u);
+    // loop A streams every rotation key exactly once per query: give it a packed shadow (6-byte residues for the < 2^48 limbs)
+    bool pack = rot_packed && prm.dim > 1;
+    for (int j = 1; j < nQ; j++)
+        if (q[j] >> 48) pack = false;
+    const size_t kb = hk::key_packed_bytes(N, nQ, nT, prm.dnum);
+    if (d_rotpack) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        (void)hipFree(d_rotpack);
+        d_rotpack = nullptr;
+    }
+    if (pack && hipMalloc((void **)&d_rotpack, kb * (size_t)(prm.dim - 1)) != hipSuccess) {
+        d_rotpack = nullptr;  // not enough HBM for the shadow: loop A reads the plain keys
+        pack = false;
+    }
     for (int i = 1; i < prm.dim; i++) {
         auto it = rot_keys.find(i);
         if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(i) + " not loaded");
-        ptrs[i] = it->second.d;
+        if (pack) {
+            hk::key_pack(stream, N, nQ, nT, prm.dnum, it->second.d, d_rotpack + kb * (size_t)(i - 1));
+            ptrs[i] = reinterpret_cast<const u64 *>(d_rotpack + kb * (size_t)(i - 1));
+        } else {
+            ptrs[i] = it->second.d;
+        }
         gal[i] = (unsigned)galois_elt(i);
         u64 x = 1;
         for (int it = 0; it < 6; it++) x = x * (2 - (u64)gal[i] * x);
         ginv[i] = (unsigned)(x & (2ull * N - 1));
     }
+    rotptrs_packed = pack;
+    HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipMemcpy(d_rotginv, ginv.data(), sizeof(unsigned) * prm.dim, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy((void *)d_rotptrs, ptrs.data(), sizeof(u64 *) * prm.dim, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_rotgalois, gal.data(), sizeof(unsigned) * prm.dim, hipMemcpyHostToDevice));
@@ -475,7 +496,7 @@ Ct Context::rotate_query(const Ct &qc) {
     HIP_CHECK(hipMemcpyAsync(rot.d, qc.d, qc.bytes(), hipMemcpyDeviceToDevice, stream));
     if (dim > 1)
         ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + 1, d_rotginv + 1, 0, false,
-                 rot.d + rot.ct_elems());
+                 rot.d + rot.ct_elems(), rotptrs_packed ? nQ : 0);
     pool.put(dig);
     return rot;
 }

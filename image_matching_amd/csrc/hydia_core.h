@@ -118,7 +118,9 @@ struct Context : HostParams {
     const u64 **d_rotptrs = nullptr;   // device array: key pointers of rotations 1..dim-1 (hoisted loop A)
     unsigned *d_rotgalois = nullptr;   // device array: their Galois elements
     unsigned *d_rotginv = nullptr;     // device array: inverse Galois elements (scatter form of the automorphism)
-    bool rotptrs_valid = false;
+    bool rotptrs_valid = false, rotptrs_packed = false;
+    unsigned char *d_rotpack = nullptr;  // packed shadow of rotation keys 1..dim-1 (45/46-bit limbs as 6-byte residues), loop A only
+    bool rot_packed = true;              // HYDIA_KEYS_UNPACKED turns the shadow off
     void load_eval_key(int rot /* 0 = relinearisation */, const u64 *host);
     u64 *eval_key_storage(int rot);    // allocates (or returns) the HBM buffer of key `rot`
     u64 *d_sk = nullptr;               // [nT][N] (receiver side only)
@@ -158,9 +160,10 @@ struct Context : HostParams {
     void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true, bool p1_only = false);
     bool fuse_ip = true;  // relinearisation: second NTT pass of ModUp fused with the inner product (HYDIA_NO_FUSE_IP)
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
+    // keys_packed_nQ > 0: d_keys point at packed keys (hk::key_pack)
     void ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const u64 *const *d_keys, int same_key,
                   const u64 *addend, size_t add_x_stride, size_t add_poly_stride, int add_polys, const unsigned *d_galois,
-                  const unsigned *d_ginv, int same_galois, bool dbl, u64 *out);
+                  const unsigned *d_ginv, int same_galois, bool dbl, u64 *out, int keys_packed_nQ = 0);
     void build_rotptrs();
     void relinearize(Ct &c, bool dbl = false);  // [X][3][nl] -> [X][2][nl]; dbl: result doubled (2ab of a Chebyshev step)
     // drop the last limb; optionally fused: result -= sub (a view at the new level), result += addc (constant, poly 0)

@@ -155,7 +155,10 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
 // (same_key: every x uses keys[0])
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dig_x_stride, int nd,
                    const u64 *const *keys, int same_key, int nT, u64 *acc, int X, const LimbSel &esel,
-                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0, int acc_rows = 0);
+                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0, int acc_rows = 0, int packed_nQ = 0);
+// packed evaluation keys (loop A): 45/46-bit limbs as 6-byte residues; packed_nQ > 0 tells inner_product that keys[] are packed
+size_t key_packed_bytes(int N, int nQ, int nT, int nd);
+void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out);
 // second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every
 // extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2)
 void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,

@@ -295,23 +295,65 @@ __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ m
         *reinterpret_cast<ulonglong2 *>(out + (size_t)x * oo + (size_t)t * N + c) = r;
     }
 }
-// grid (N/512, nE, X); 2 coefficients per thread, both key polys
+// two consecutive residues of an 8-byte (PK = false) or 6-byte (PK = true) row; NT: non-temporal load
+template <bool PK, bool NT>
+DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
+    if (!PK) {
+        const ull2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(p)) : *reinterpret_cast<const ull2 *>(p);
+        ulonglong2 r;
+        r.x = v.x;
+        r.y = v.y;
+        return r;
+    }
+    const u3 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(p)) : *reinterpret_cast<const u3 *>(p);
+    ulonglong2 r;
+    r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
+    r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
+    return r;
+}
+
+// packed key layout (loop A's rotation keys): per (digit, poly) one row set — modulus 0 as N 8-byte residues, the nQ-1 scaling
+// moduli (< 2^48) as N 6-byte residues each, then the nP special moduli as N 8-byte residues.  -17 % of the 12 GiB key stream.
+HD size_t key_limb_offset(int N, int nQ, int m) {
+    return m == 0 ? 0 : (m < nQ ? (size_t)N * 8 + (size_t)(m - 1) * N * 6 : (size_t)N * 8 + (size_t)(nQ - 1) * N * 6 + (size_t)(m - nQ) * N * 8);
+}
+HD size_t key_set_bytes(int N, int nQ, int nT) { return key_limb_offset(N, nQ, nT); }
+// grid (N/512, nE, X); 2 coefficients per thread, both key polys.  PK: keys[x] points at a packed key (see above)
+template <bool PK>
 __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ mod, int N, const u64 *__restrict__ dig,
                                                        size_t dxs, int nd, const u64 *const *__restrict__ keys,
                                                        int same_key, int nT, u64 *__restrict__ acc, LimbSel esel,
-                                                       const u64 *__restrict__ own, size_t own_xs, int alpha, int nl, int acc_rows) {
+                                                       const u64 *__restrict__ own, size_t own_xs, int alpha, int nl, int acc_rows,
+                                                       int nQ) {
     const int t = blockIdx.y, x = blockIdx.z, nE = acc_rows, m = esel.mod[t];
     const ModC M = mod[m];
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     const u64 *key = keys[same_key ? 0 : x];
+    const bool six = PK && m > 0 && m < nQ;
+    const unsigned char *kbytes = reinterpret_cast<const unsigned char *>(key) + (PK ? key_limb_offset(N, nQ, m) : 0) + c * (six ? 6 : 8);
+    const size_t set_bytes = PK ? key_set_bytes(N, nQ, nT) : 0;
     u128 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
     for (int d = 0; d < nd; d++) {
         // a digit's own limbs are the input itself (evaluation form): read them in place when the caller did not copy them
         const u64 *src = (own && t < nl && t / alpha == d) ? own + (size_t)x * own_xs + (size_t)t * N + c
                                                            : dig + (size_t)x * dxs + ((size_t)d * nE + t) * N + c;
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
-        const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 0) * nT + m) * N + c);
-        const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 1) * nT + m) * N + c);
+        ulonglong2 kb, ka;
+        if (PK) {
+            const unsigned char *pb = kbytes + (size_t)(d * 2) * set_bytes, *pa = pb + set_bytes;
+            if (six) {
+                kb = db_load2<true, false>(pb);
+                ka = db_load2<true, false>(pa);
+            } else {
+                kb = db_load2<false, false>(pb);
+                ka = db_load2<false, false>(pa);
+            }
+        } else {
+            kb = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 0) * nT + m) * N + c);
+            ka = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)d * 2 + 1) * nT + m) * N + c);
+        }
         a0x += (u128)v.x * kb.x;
         a0y += (u128)v.y * kb.y;
         a1x += (u128)v.x * ka.x;
@@ -324,6 +366,24 @@ __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ 
     r1.y = reduce_lazy(a1y, M, nd);
     *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 0) * nE + t) * N + c) = r0;
     *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 1) * nE + t) * N + c) = r1;
+}
+// [nd][2][nT][N] u64 -> packed key.  grid (N/512, nT, nd*2)
+__global__ __launch_bounds__(256) void k_key_pack(int N, int nQ, int nT, const u64 *__restrict__ key, unsigned char *__restrict__ out) {
+    const int m = blockIdx.y, dp = blockIdx.z;
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(key + ((size_t)dp * nT + m) * N + c);
+    const bool six = m > 0 && m < nQ;
+    unsigned char *d = out + (size_t)dp * key_set_bytes(N, nQ, nT) + key_limb_offset(N, nQ, m) + c * (six ? 6 : 8);
+    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
+    if (six) {
+        u3 w;
+        w.x = (unsigned)v.x;
+        w.y = (unsigned)(v.x >> 32) | ((unsigned)v.y << 16);
+        w.z = (unsigned)(v.y >> 16);
+        *reinterpret_cast<u3 *>(d) = w;
+    } else {
+        *reinterpret_cast<ulonglong2 *>(d) = v;
+    }
 }
 // grid (N/256, nl, X*2)
 __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict__ mod, int logN,
@@ -446,24 +506,6 @@ __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict_
 HD size_t db_limb_offset(const DbLayout &L, int N, int j) {
     return L.packed ? (j == 0 ? 0 : (size_t)N * 8 + (size_t)(j - 1) * N * 6) : (size_t)j * N * 8;
 }
-template <bool PK, bool NT>
-DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
-    if (!PK) {
-        const ull2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(p)) : *reinterpret_cast<const ull2 *>(p);
-        ulonglong2 r;
-        r.x = v.x;
-        r.y = v.y;
-        return r;
-    }
-    const u3 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(p)) : *reinterpret_cast<const u3 *>(p);
-    ulonglong2 r;
-    r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
-    r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
-    return r;
-}
-
 // One Karatsuba step per coefficient: d0 += a0 b0, d2 += a1 b1, dk += (a0+a1)(b0+b1); d1 = dk - d0 - d2 at the end.
 // Three 64x64->128 products per coefficient instead of four — loop B is co-bound by the integer multiplier, not only
 // by HBM (gfx950 builds a 128-bit product from four v_mad_u64_u32).
@@ -638,9 +680,17 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
                    int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl,
-                   int acc_rows) {
-    hipLaunchKernelGGL(k_inner_product, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
-                       nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n);
+                   int acc_rows, int packed_nQ) {
+    if (packed_nQ > 0)
+        hipLaunchKernelGGL(k_inner_product<true>, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
+                           nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n, packed_nQ);
+    else
+        hipLaunchKernelGGL(k_inner_product<false>, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
+                           nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n, 0);
+}
+size_t key_packed_bytes(int N, int nQ, int nT, int nd) { return (size_t)nd * 2 * key_set_bytes(N, nQ, nT); }
+void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out) {
+    hipLaunchKernelGGL(k_key_pack, dim3(N / 512, nT, nd * 2), dim3(256), 0, st, N, nQ, nT, key, (unsigned char *)out);
 }
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
                      const u64 *addend, size_t axs, size_t aps, int add_polys, u64 *out, int X, int nl,

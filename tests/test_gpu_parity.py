@@ -271,12 +271,13 @@ def test_custom_prime_chain_context_bit_exact(im):
 
 def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     """Every fast-path decision at N = 2^15 is bit-neutral: the default engine (FP64 NTT butterflies on the 45-bit limbs, 48-bit
-    packed database, merged ModDown+Rescale, NTT pass 2 fused with the inner product, two comparator lanes) and the plain one
-    (integer butterflies everywhere, 8-byte database, separate relinearise / rescale, unfused inner product, one lane) give
+    packed database and rotation keys, merged ModDown+Rescale, NTT pass 2 fused with the inner product, two comparator lanes) and the plain one
+    (integer butterflies everywhere, 8-byte database and keys, separate relinearise / rescale, unfused inner product, one lane) give
     identical residues for a 3-block database (batched X = 3 evaluator ops, uneven lane split) — index, membership and scores."""
     variants = [
         {},
-        {"HYDIA_NTT_INT": "1", "HYDIA_DB_UNPACKED": "1", "HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "1"},
+        {"HYDIA_NTT_INT": "1", "HYDIA_DB_UNPACKED": "1", "HYDIA_KEYS_UNPACKED": "1", "HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1",
+         "HYDIA_LANES": "1"},
         {"HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "3"},
     ]
     n = 40000
@@ -286,7 +287,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         db[i] = rng.integers(1, 4, size=512)
     results = []
     for env in variants:
-        for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES"):
+        for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
