@@ -3,12 +3,13 @@
 
 A "step" is ONE query through DiagonalSender::indexScenario (/root/reference/src/sender/sender_diag.cpp:52-63: 511 hoisted
 rotations, per block 512 tensor products + 1 relinearise + 1 rescale, degree-59 Chebyshev o f4 comparator) over the
-encrypted database resident in this rank's HBM, plus — for N > 1 — the RCCL gather of the result ciphertexts to rank 0.
-The database is sharded by 16384-vector row-blocks: every rank owns its own blocks and runs an independent mat-vec
-(no data-path collective); per-GPU work is fixed as N grows ("weak").  Data is synthetic with the distribution of the
-reference's tools/gen_dataset.sh (query = ones, random rows in [-99,99], planted matches in {1,2,3}); the database is
-REAL ciphertexts produced by the on-GPU enroller, and after the timed region the decrypted index result is checked
-against the planted matches.
+encrypted database resident in HBM.  For N > 1 the database is sharded by 16384-vector row-blocks over the ranks and the step
+runs through image_matching_amd.sharding.DistDiagonalSender — the same class the tests pin bit-exactly against one context:
+rank 0's query is broadcast, every rank runs an independent mat-vec + comparator on its own blocks (no data-path collective),
+and the result ciphertexts are gathered over RCCL to rank 0 in global block order.  Per-GPU work is fixed as N grows ("weak").
+Data is synthetic with the distribution of the reference's tools/gen_dataset.sh (query = ones, random rows in [-99,99], planted
+matches in {1,2,3}); the database is REAL ciphertexts produced by the on-GPU enroller, and after the timed region rank 0
+decrypts the gathered index result and checks it against the planted matches (global indices).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -17,7 +18,10 @@ against the planted matches.
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,44 +36,106 @@ sys.path.insert(0, ROOT)
 
 SEED = 20250725
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PUBLISHED_2P20_INDEX_VPS = (1 << 20) / 96.52172  # /root/reference/tools/figures/approach5.csv:12 (Xeon Gold 5412U, 48 threads)
 
 
-def synth_db(n, dim, rank, planted):
-    """tools/gen_dataset.sh distribution: rows uniform integers in [-99, 99]; matching rows uniform in {1,2,3}."""
-    rng = np.random.default_rng(SEED + 1000 * rank)
-    db = rng.integers(-99, 100, size=(n, dim), dtype=np.int8).astype(np.float64)
-    for i in planted:
-        db[i] = rng.integers(1, 4, size=dim)
-    return db
+def synth_rows(lo, hi, dim, planted):
+    """Rows [lo, hi) of the synthetic database (tools/gen_dataset.sh distribution: uniform integers in [-99, 99]; matching rows
+    uniform in {1,2,3}).  Generated per 16384-row block from a seed that depends on the GLOBAL block index, so any sharding of
+    the same database enrols the same vectors."""
+    out = np.empty((hi - lo, dim), dtype=np.float64)
+    S = 16384
+    for b in range(lo // S, -(-hi // S)):
+        rng = np.random.default_rng(SEED + 1000003 * b)
+        blk = rng.integers(-99, 100, size=(S, dim), dtype=np.int8).astype(np.float64)
+        for i in planted:
+            if b * S <= i < (b + 1) * S:
+                blk[i - b * S] = rng.integers(1, 4, size=dim)
+        a, z = max(lo, b * S), min(hi, (b + 1) * S)
+        out[a - lo:z - lo] = blk[a - b * S:z - b * S]
+    return out
 
 
-def cpu_baseline(dim_full=512):
-    """Time the CPU oracle (the build's restatement of the reference algorithm; OpenFHE itself is absent) on this host:
-    one full indexScenario over ONE 16384-vector block at the real ring.  Only this leg touches oracle/."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """Time the CPU oracle (this repository's restatement of the reference algorithm — OpenFHE itself is absent, kind "port")
+    on this host's cores, the way BASELINE.md §2 prescribes: the same indexScenario at G = 1 and G = 3 blocks in RAM, the
+    marginal seconds per extra 16384-vector block, the linear extrapolation to the 64 blocks of 2^20 vectors (the published
+    curve is linear in blocks, tools/figures/approach5.csv), plus one G = 1 query whose loop B re-reads every ciphertext from
+    disk like the reference's timed loop (sender_diag.cpp:87-91).  Only this leg touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     P = O.Params()
     K = O.Keys(P, SEED)
     Or = O.Oracle(P, K)
-    n = P.slots
-    db = synth_db(n, P.dim, 99, [5])
+    S, n3 = P.slots, 3 * P.slots
+    planted = [5, S + 9, n3 - 1]
+    db = synth_rows(0, n3, P.dim, planted)
     dbc = Or.enroll(db, 99)
     q = Or.encrypt_query(np.ones(P.dim), 5, 1)
-    t0 = time.time()
-    rot = Or.rotate_query(q)
-    t_rot = time.time() - t0
+
+    def timed(fn):
+        t0 = time.time()
+        r = fn()
+        return time.time() - t0, r
+    t_rot, rot = timed(lambda: Or.rotate_query(q))
     del rot
-    t0 = time.time()
-    idx = Or.index_scenario(q, dbc, n)
-    t_index = time.time() - t0
-    ok = Or.decrypt_index(idx) == [5]
-    cores = O.lib().hyo_num_threads()
+    t1, idx1 = timed(lambda: Or.index_scenario(q, dbc, S))
+    ok = Or.decrypt_index(idx1) == [5]
+    t3, idx3 = timed(lambda: Or.index_scenario(q, dbc, n3))
+    ok = ok and Or.decrypt_index(idx3) == planted
+    marginal = (t3 - t1) / 2.0
+    t_2p20 = t1 + 63 * marginal
+    disk = None
+    d = tempfile.mkdtemp(prefix="hydia_serial_")
+    try:
+        free = shutil.disk_usage(d).free
+        if free > 5 << 30:
+            sub = O.CtArray(P, dbc.h, P.dim)  # the first block's 512 ciphertexts (a view: never freed through `sub`)
+            try:
+                Or.write_db_files(sub, d)
+            finally:
+                sub.h = None
+            td, idxd = timed(lambda: Or.index_scenario_files(q, d, S))
+            ok = ok and Or.decrypt_index(idxd) == [5]
+            disk = {"s_per_query_G1": round(td, 3), "vectors_per_s_G1": round(S / td, 1),
+                    "note": "loop B reads index<t>.bin (6 MiB each, page cache warm) inside the parallel loop"}
+    except Exception as e:  # no scratch space on this box: the RAM figure stands alone
+        disk = {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    cores = int(O.lib().hyo_num_threads())
     return {
-        "value": n / t_index, "unit": "vectors/s", "cores": int(cores), "kind": "port",
-        "sample": "one indexScenario over ONE 16384-vector block at N=2^15 (511 hoisted rotations + 512 tensor products + "
-                  "relin + rescale + compare): %.2f s, of which rotations %.2f s; OpenMP over the reference's loops; "
-                  "result %s" % (t_index, t_rot, "correct" if ok else "WRONG"),
+        "value": (1 << 20) / t_2p20, "unit": "vectors/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model(), "omp_max_threads": cores, "host_logical_cpus": os.cpu_count(),
+        "sample": "oracle indexScenario at N=2^15 timed at G=1 (%.2f s, of which the 511 hoisted rotations %.2f s) and G=3 (%.2f s) "
+                  "blocks of 16384 vectors, DB in RAM: marginal %.3f s per block; value = 2^20 / (t_G1 + 63 x marginal) = linear "
+                  "extrapolation to the 64 blocks of the GPU workload (%.1f s per query); results %s"
+                  % (t1, t_rot, t3, marginal, t_2p20, "correct" if ok else "WRONG"),
+        "s_per_query": {"G1": round(t1, 3), "G3": round(t3, 3), "marginal_per_block": round(marginal, 3),
+                        "extrapolated_2p20": round(t_2p20, 2)},
+        "vectors_per_s_measured": {"G1": round(S / t1, 1), "G3": round(n3 / t3, 1)},
+        "disk_reread_variant": disk,
+        "published_anchor": {"vectors_per_s": round(PUBLISHED_2P20_INDEX_VPS, 1),
+                             "what": "reference's own 2^20 index computation, 96.52 s on Xeon Gold 5412U / 48 threads incl. disk reads "
+                                     "(tools/figures/approach5.csv:12)"},
     }
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except Exception:
+        return ""
 
 
 def main():
@@ -77,9 +143,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log2n", type=int, default=20, help="log2 of DB vectors PER GPU (default 2^20 = 192 GiB of ciphertexts)")
+    ap.add_argument("--log2n", type=int, default=20, help="log2 of DB vectors PER GPU (default 2^20 = 148 GiB resident, 192 GiB unpacked)")
     ap.add_argument("--total-log2n", type=int, default=None,
-                    help="strong-scaling variant (BASELINE configs 4/5): log2 of the TOTAL DB vectors, split evenly over the ranks")
+                    help="strong-scaling variant (BASELINE configs 4/5): log2 of the TOTAL DB vectors, split over the ranks by blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-db", action="store_true", help="fill the DB with random residues instead of enrolling")
     args = ap.parse_args()
@@ -88,11 +154,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = torch = None
-    # HYDIA_BENCH_REHEARSE=1: every rank computes on GPU 0 and the gather goes through gloo/host memory — lets the multi-rank
+    # HYDIA_BENCH_REHEARSE=1: every rank computes on GPU 0 and the collectives go through gloo/host memory — lets the multi-rank
     # control flow be exercised on a one-GPU box (never used for reported numbers)
     rehearse = os.environ.get("HYDIA_BENCH_REHEARSE") == "1"
     # HYDIA_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1): take the multi-rank path with a one-rank RCCL group — exercises
-    # the real nccl init / gather / device-pointer plumbing on a one-GPU box
+    # the real nccl init / collectives / device-pointer plumbing on a one-GPU box
     multi = world > 1 or os.environ.get("HYDIA_BENCH_FORCE_DIST") == "1"
     if multi:
         import torch  # noqa: F811  (device memory + RCCL only)
@@ -106,42 +172,31 @@ def main():
     import image_matching_amd as im
     cc = im.Context(im.default_params(), 0 if rehearse else local_rank)
     strong = args.total_log2n is not None
-    n = (1 << args.total_log2n) // world if strong else 1 << args.log2n
+    n_total = (1 << args.total_log2n) if strong else world * (1 << args.log2n)
     dim, S = cc.dim, cc.slots
-    G = -(-n // S)
+    first, last = im.shard_vectors(n_total, S, world, rank)
+    n_local = last - first
+    G_local = -(-n_local // S)
 
     t0 = time.time()
     cc.keygen(SEED)  # same seed on every rank -> identical keys, no key distribution needed
     t_keygen = time.time() - t0
-    planted = sorted(set([0, n // 2, n - 1])) if n > 2 else [0]
+    planted = sorted(set([0, n_total // 2, n_total - 1])) if n_total > 2 else [0]
     t0 = time.time()
     if args.random_db:
-        cc.db_fill_random(n, SEED + rank)
+        if n_local:
+            cc.db_fill_random(n_local, SEED + rank)
     else:
-        db = synth_db(n, dim, rank, planted)
-        im.DiagonalEnroller(cc, n).serializeDB(db, seed=SEED + 7 * rank)
-        del db
+        rows = synth_rows(first, last, dim, planted)
+        im.DistDiagonalEnroller(cc, n_total, rank, world).serializeDB(rows, seed=SEED + 7)
+        del rows
     t_enroll = time.time() - t0
-    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
-    qc = receiver.encryptQuery(np.ones(dim), seed=SEED, nonce=1)
-
-    gather_buf = gather_list = None
-
-    def step():
-        res = sender.indexScenario(qc)
-        if multi:
-            nonlocal gather_buf, gather_list
-            cnt, npoly, nl, _ = res.shape()
-            if rehearse:
-                gather_buf = torch.from_numpy(res.export().view(np.int64).reshape(-1))
-                gather_list = [torch.empty_like(gather_buf) for _ in range(world)] if rank == 0 else None
-            else:
-                if gather_buf is None:
-                    gather_buf = torch.empty(cnt * npoly * nl * cc.N, dtype=torch.int64, device="cuda")
-                    gather_list = [torch.empty_like(gather_buf) for _ in range(world)] if rank == 0 else None
-                res.copy_to_device(gather_buf.data_ptr())
-            dist.gather(gather_buf, gather_list, dst=0)
-        return res
+    receiver = im.DiagonalReceiver(cc, n_total)
+    qc = receiver.encryptQuery(np.ones(dim), seed=SEED, nonce=1) if rank == 0 else None
+    if multi:
+        sender = im.DistDiagonalSender(cc, n_total, dist, rank, world, staging="host" if rehearse else "device")
+    else:
+        sender = im.DiagonalSender(cc, n_total)
 
     def fence():
         cc.sync()
@@ -153,18 +208,20 @@ def main():
                 torch.cuda.synchronize()
 
     if multi and not rehearse:
-        # open the RCCL send/recv channels of the gather outside the timed region even when --warmup 0 (lazy connection
-        # set-up takes seconds; it is communicator start-up, not part of a query)
+        # open the RCCL channels outside the timed region even when --warmup 0 (lazy connection set-up takes seconds; it is
+        # communicator start-up, not part of a query)
         probe = torch.zeros(1024, dtype=torch.int64, device="cuda")
+        dist.broadcast(probe, src=0)
         dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
         torch.cuda.synchronize()
+    res = None
     for _ in range(args.warmup):
-        step()
+        res = sender.indexScenario(qc)
     fence()
     cc.kernel_time_reset()
     t0 = time.time()
     for _ in range(args.steps):
-        res = step()
+        res = sender.indexScenario(qc)
     fence()
     elapsed = time.time() - t0
     if multi:
@@ -174,78 +231,103 @@ def main():
 
     ms_tensor, launches = cc.kernel_time("hydia_tensor")
     # secondary figure of SURVEY 8d (outside the timed region): computeSimilarity alone = loop A + loop B + relin + rescale
-    cc.sync()
-    t1 = time.time()
-    for _ in range(3):
-        sim = sender.computeSimilarity(qc)
-    cc.sync()
-    ms_similarity = (time.time() - t1) / 3 * 1e3
-    del sim
-    # correctness of what was just timed: decrypt this rank's index result (rank 0 also decrypts the gathered ones)
+    ms_similarity = None
+    if not multi:
+        cc.sync()
+        t1 = time.time()
+        for _ in range(3):
+            sim = sender.computeSimilarity(qc)
+        cc.sync()
+        ms_similarity = (time.time() - t1) / 3 * 1e3
+        del sim
+    # correctness of what was just timed: rank 0 holds every block's result in global block order -> global indices
     correct = True
-    if not args.random_db:
-        correct = receiver.decryptIndex(res) == planted
-        if multi and rank == 0:
-            cnt, npoly, nl, scale = res.shape()
-            for r in range(1, world):
-                if rehearse:
-                    other = cc.import_ct(gather_list[r].numpy().view(np.uint64).reshape(cnt, npoly, nl, cc.N), scale)
-                else:
-                    other = cc.ct_from_device(gather_list[r].data_ptr(), cnt, npoly, nl, scale)
-                correct = correct and receiver.decryptIndex(other) == planted
+    if not args.random_db and rank == 0 and res is not None:
+        correct = receiver.decryptIndex(res) == planted and len(res) == -(-n_total // S)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        algo_bytes = (G * dim + dim) * 2 * cc.nQ * cc.N * 8 + G * 3 * cc.nQ * cc.N * 8
+        nl, N = cc.nQ, cc.N
+        algo_bytes = (G_local * dim + dim) * 2 * nl * N * 8 + G_local * 3 * nl * N * 8
         avg_launch_s = ms_tensor / max(launches, 1) / 1e3
         achieved = algo_bytes / avg_launch_s / 1e9 if launches else 0.0
-        traffic = None
+        # bytes the kernel has to move given the RESIDENT layout (48-bit residues for the 45/46-bit limbs of the database;
+        # rotated queries and accumulators at 8 bytes): what the wire sees when nothing is read twice
+        resident_bytes = cc.db_stats()[2] + dim * 2 * nl * N * 8 + G_local * 3 * nl * N * 8
+        wire = resident_bytes / avg_launch_s / 1e9 if launches else 0.0
+        traffic = traffic_meta = None
         tpath = os.path.join(ROOT, "profiles", "tensor_traffic.json")
-        if os.path.exists(tpath):
+        knobs = [k for k in ("HYDIA_DB_UNPACKED", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW") if os.environ.get(k)]
+        if os.path.exists(tpath) and not args.random_db and not knobs and not strong:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("log2n") == args.log2n and not strong:
+                if tj.get("log2n") == args.log2n:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_meta = {"profiled_at_commit": tj.get("commit"), "source": tj.get("source"),
+                                    "kernel_source_sha": tj.get("kernel_sha"), "stale": tj.get("kernel_sha") != kernel_sha()}
+                    if traffic_meta["stale"]:
+                        traffic = None  # the loop-B kernel changed since the counters were collected: do not quote them
             except Exception:
                 traffic = None
+        db_gib = cc.db_stats()[2] / 2 ** 30
         out = {
             "metric": "encrypted DB vectors matched/sec (HyDia indexScenario, CKKS N=2^15)",
-            "value": world * n * args.steps / elapsed,
+            "value": n_total * args.steps / elapsed,
             "unit": "vectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": (n_total * args.steps / elapsed) / PUBLISHED_2P20_INDEX_VPS if (world == 1 and n_total == 1 << 20) else None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB per GPU (%d blocks of 16384, "
-                                   "%.0f GiB of ciphertexts resident in HBM), one query per step through indexScenario"
-                                   % (n.bit_length() - 1, G, G * dim * 2 * cc.nQ * cc.N * 8 / 2 ** 30),
-                       "db_vectors_total": world * n, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
-                       "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3", "sharding": "row-block per GPU, RCCL gather of results",
-                       "db_storage": "%.1f GiB resident (45/46-bit limbs held as 48-bit residues)" % (cc.db_stats()[2] / 2 ** 30),
-                       "result_check": "decrypted index == planted matches" if not args.random_db else "skipped (random DB)",
+            "config": {"workload": "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB per GPU (%d blocks of 16384; %.0f GiB resident in "
+                                   "HBM as 48-bit residues = %.0f GiB of 8-byte ciphertexts), one query per step through indexScenario"
+                                   % (max(n_local, 1).bit_length() - 1, G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30),
+                       "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
+                       "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
+                       "sharding": "row-blocks per GPU (image_matching_amd.sharding.DistDiagonalSender): query broadcast, independent "
+                                   "mat-vec per rank, RCCL gather of result ciphertexts in global block order" if multi else "one GPU",
+                       "result_check": "decrypted index of the gathered result == planted matches (global indices)" if not args.random_db else "skipped (random DB)",
                        "result_correct": bool(correct), "setup_s": {"keygen": round(t_keygen, 2), "enroll": round(t_enroll, 2)},
-                       "secondary": {"computeSimilarity_ms_per_query_rank0": round(ms_similarity, 3),
-                                     "computeSimilarity_vectors_per_s_per_gpu": round(n / ms_similarity * 1e3)}},
+                       "vs_baseline_note": "value / 10 864 vectors/s = the reference's published 2^20 index computation on a 48-thread Xeon "
+                                           "(tools/figures/approach5.csv:12); null unless this run is that workload on one GPU",
+                       "commit": git_head()},
             "roofline": {"kernel": "k_hydia_tensor", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches": int(launches),
-                         "note": "algorithmic bytes = SURVEY 8d figure (196608 B per DB vector at 8 B per residue) + rotated queries + "
-                                 "accumulators; one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two kernels); traffic = PMC "
-                                 "HBM bytes per launch (profiles/tensor_traffic.json), below the algorithmic bytes because the database's "
-                                 "45/46-bit limbs are resident as 48-bit residues; traffic_rate = traffic / launch time in GB/s, to be read "
-                                 "against the guide's measured 6.29 TB/s copy ceiling"},
+                         "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None, "traffic_meta": traffic_meta,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
+                         "wire": {"bytes_per_launch": resident_bytes, "achieved": wire, "frac": wire / HBM_PEAK_GBS,
+                                  "what": "resident-layout bytes (6-byte residues for the 45/46-bit limbs) / launch time: the rate HBM "
+                                          "actually has to sustain; against the guide's measured 6.29 TB/s copy ceiling this is %.2f"
+                                          % (wire / 6290.0)},
+                         "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8d (196608 B per DB vector at 8 B per residue + rotated "
+                                 "queries + accumulators); one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two "
+                                 "kernels, timed together with HIP events on the library's stream); `wire` is the same launch priced "
+                                 "at the bytes resident in HBM; `traffic` = PMC HBM bytes per launch (profiles/tensor_traffic.json), quoted "
+                                 "only while the kernel source it was profiled on is unchanged"},
         }
+        if ms_similarity is not None:
+            out["config"]["secondary"] = {"computeSimilarity_ms_per_query": round(ms_similarity, 3),
+                                          "computeSimilarity_vectors_per_s": round(n_local / ms_similarity * 1e3)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    del res, qc
     cc.close()
     if not correct:
         sys.exit(3)
+
+
+def kernel_sha():
+    """identifies the loop-B kernel the committed PMC traffic figure belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    text = open(os.path.join(ROOT, "image_matching_amd", "csrc", "kernels.hip")).read()
+    i = text.find("k_hydia_tensor")
+    h.update(text[max(0, i - 4000):i + 6000].encode())
+    return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":

@@ -4,40 +4,22 @@
 #include <cstdio>
 #include <cstring>
 
-#include "../../include/hydia.h"
-#include "client.h"
-#include "hydia_core.h"
+#include <sys/random.h>
+
+#include "capi_internal.h"
 
 using namespace hydia;
 
-struct hydia_ctx {
-    Context cx;
-    hydia_ctx(const Params &p, int dev) : cx(p, dev) {}
-};
-struct hydia_ct {
-    Ct c;
-};
-
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) {
+int hydia_fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
-#define API_BEGIN try {
-#define API_END                                                          \
-    }                                                                    \
-    catch (const std::runtime_error &e) {                                \
-        std::string m = e.what();                                        \
-        int code = m.find("hip") != std::string::npos ? HYDIA_ERR_DEVICE \
-                   : m.find("not loaded") != std::string::npos || m.find("no database") != std::string::npos ||  \
-                     m.find("must be a fresh") != std::string::npos ? HYDIA_ERR_STATE : HYDIA_ERR_ARG;            \
-        return fail(code, m);                                            \
-    }                                                                    \
-    catch (const std::exception &e) { return fail(HYDIA_ERR_INTERNAL, e.what()); }
-#define REQUIRE(cond, msg) \
-    if (!(cond)) return fail(HYDIA_ERR_ARG, msg)
+#define fail hydia_fail
+// the nonce is a 40-bit field of the sampler stream id (client_kernels.h HY_STREAM): a larger value would bleed into the domain byte
+#define HYDIA_NONCE_LIMIT (1ull << 40)
 
-static Params to_params(const hydia_params *p) {
+Params hydia_to_params(const hydia_params *p) {
     Params r;
     r.logN = (int)p->log_n;
     r.mult_depth = (int)p->mult_depth;
@@ -51,19 +33,30 @@ static void fill_info(const HostParams &h, hydia_info *o) {
     o->log_n = h.prm.logN; o->n = h.N; o->slots = h.slots; o->n_q = h.nQ; o->n_p = h.nP; o->dnum = h.prm.dnum;
     o->alpha = h.alpha; o->vector_dim = h.prm.dim; o->delta = h.delta;
 }
-// handles that cross the C-ABI are always compact ([count][poly][limb][N], nl == lstride) and owning
-static hydia_ct *wrap(Ct &&c) {
-    hydia_ct *h = new hydia_ct;
-    if (c.view || !c.compact()) h->c = c.ctx->clone(c);
-    else h->c = std::move(c);
-    return h;
-}
-
 extern "C" {
 
 const char *hydia_last_error(void) { return g_err.c_str(); }
 const char *hydia_version(void) { return "hydia-mi355x 0.1 (gfx950)"; }
 
+/* 32 bytes from the operating system's entropy pool (getrandom(2), /dev/urandom as fall-back): what every role object
+ * seeds its encryption randomness from unless the caller supplies a seed of its own */
+int hydia_random_seed(uint8_t out[32]) {
+    if (!out) return fail(HYDIA_ERR_ARG, "null argument");
+    size_t got = 0;
+    while (got < 32) {
+        ssize_t r = getrandom(out + got, 32 - got, 0);
+        if (r <= 0) break;
+        got += (size_t)r;
+    }
+    if (got < 32) {
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (f) {
+            got += fread(out + got, 1, 32 - got, f);
+            fclose(f);
+        }
+    }
+    return got == 32 ? HYDIA_OK : fail(HYDIA_ERR_INTERNAL, "hydia: no entropy source (getrandom and /dev/urandom failed)");
+}
 void hydia_default_params(hydia_params *o) {
     o->log_n = 15;
     o->mult_depth = (uint32_t)hydia_compute_required_depth(5);
@@ -87,7 +80,7 @@ size_t hydia_compute_required_depth(size_t approach) {
 int hydia_params_describe(const hydia_params *p, hydia_info *info, uint64_t *moduli, uint64_t *roots) {
     API_BEGIN
     REQUIRE(p, "null params");
-    HostParams h(to_params(p));
+    HostParams h(hydia_to_params(p));
     if (info) fill_info(h, info);
     for (int m = 0; m < h.nT; m++) {
         if (moduli) moduli[m] = h.q[m];
@@ -103,7 +96,7 @@ int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
     REQUIRE(device >= 0 && device < ndev, "bad device index");
-    *out = new hydia_ctx(to_params(p), device);
+    *out = new hydia_ctx(hydia_to_params(p), device);
     return HYDIA_OK;
     API_END
 }
@@ -116,7 +109,7 @@ int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
     REQUIRE(device >= 0 && device < ndev, "bad device index");
-    Params prm = to_params(p);
+    Params prm = hydia_to_params(p);
     prm.mult_depth = (int)n_q - 1;
     prm.custom_q.assign(moduli, moduli + n_q + n_p);
     if (roots) prm.custom_psi.assign(roots, roots + n_q + n_p);
@@ -125,7 +118,11 @@ int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const
     return HYDIA_OK;
     API_END
 }
-void hydia_ctx_destroy(hydia_ctx *ctx) { delete ctx; }
+void hydia_ctx_destroy(hydia_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->live_handles > 0) ctx->destroy_requested = true;
+    else delete ctx;
+}
 int hydia_get_info(const hydia_ctx *ctx, hydia_info *out) {
     REQUIRE(ctx && out, "null argument");
     fill_info(ctx->cx, out);
@@ -141,6 +138,7 @@ int hydia_get_moduli(const hydia_ctx *ctx, uint64_t *moduli, uint64_t *roots) {
 }
 int hydia_sync(hydia_ctx *ctx) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx, "null ctx");
     ctx->cx.sync();
     return HYDIA_OK;
@@ -157,6 +155,7 @@ int hydia_memory_stats(hydia_ctx *ctx, uint64_t *live, uint64_t *cached, uint64_
 // ------------------------------------------------------------------ keys
 int hydia_keygen(hydia_ctx *ctx, const uint8_t seed[32]) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && seed, "null argument");
     client_keygen(ctx->cx, seed);
     return HYDIA_OK;
@@ -164,6 +163,7 @@ int hydia_keygen(hydia_ctx *ctx, const uint8_t seed[32]) {
 }
 int hydia_import_eval_key(hydia_ctx *ctx, int rot, const uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data && rot >= 0 && rot < ctx->cx.slots, "bad argument");
     ctx->cx.load_eval_key(rot, (const u64 *)data);
     return HYDIA_OK;
@@ -171,6 +171,7 @@ int hydia_import_eval_key(hydia_ctx *ctx, int rot, const uint64_t *data) {
 }
 int hydia_export_eval_key(hydia_ctx *ctx, int rot, uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     Context &cx = ctx->cx;
     const u64 *src = nullptr;
@@ -184,6 +185,7 @@ int hydia_export_eval_key(hydia_ctx *ctx, int rot, uint64_t *data) {
 }
 int hydia_fill_eval_keys_random(hydia_ctx *ctx, uint64_t seed) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx, "null ctx");
     Context &cx = ctx->cx;
     std::vector<int> rots;
@@ -206,24 +208,28 @@ int hydia_has_eval_key(hydia_ctx *ctx, int rot) {
     return it != ctx->cx.rot_keys.end() && it->second.d != nullptr;
 }
 static int import_buf(Context &cx, u64 **slot, const uint64_t *data, size_t elems) {
+    if (cx.keys_borrowed) throw StateError("hydia: this context borrows its keys from another context (re-key the owner)");
     if (!*slot) HIP_CHECK(hipMalloc((void **)slot, elems * sizeof(u64)));
     HIP_CHECK(hipMemcpy(*slot, data, elems * sizeof(u64), hipMemcpyHostToDevice));
     return HYDIA_OK;
 }
 int hydia_import_public_key(hydia_ctx *ctx, const uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     return import_buf(ctx->cx, &ctx->cx.d_pk, data, (size_t)2 * ctx->cx.nQ * ctx->cx.N);
     API_END
 }
 int hydia_import_secret_key(hydia_ctx *ctx, const uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     return import_buf(ctx->cx, &ctx->cx.d_sk, data, (size_t)ctx->cx.nT * ctx->cx.N);
     API_END
 }
 int hydia_export_public_key(hydia_ctx *ctx, uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     if (!ctx->cx.d_pk) return fail(HYDIA_ERR_STATE, "hydia: public key not loaded");
     ctx->cx.sync();
@@ -233,6 +239,7 @@ int hydia_export_public_key(hydia_ctx *ctx, uint64_t *data) {
 }
 int hydia_export_secret_key(hydia_ctx *ctx, uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     if (!ctx->cx.d_sk) return fail(HYDIA_ERR_STATE, "hydia: secret key not loaded");
     ctx->cx.sync();
@@ -245,17 +252,19 @@ int hydia_export_secret_key(hydia_ctx *ctx, uint64_t *data) {
 int hydia_ct_import(hydia_ctx *ctx, const uint64_t *data, uint32_t count, uint32_t n_polys, uint32_t n_limbs, double scale,
                     hydia_ct **out) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data && out, "null argument");
     REQUIRE(count >= 1 && (n_polys == 2 || n_polys == 3) && n_limbs >= 1 && (int)n_limbs <= ctx->cx.nQ, "bad ciphertext shape");
     Ct c(&ctx->cx, (int)count, (int)n_polys, (int)n_limbs, scale);
     ctx->cx.sync();
     HIP_CHECK(hipMemcpy(c.d, data, c.bytes(), hipMemcpyHostToDevice));
-    *out = wrap(std::move(c));
+    *out = wrap(ctx, std::move(c));
     return HYDIA_OK;
     API_END
 }
 int hydia_ct_export(hydia_ctx *ctx, const hydia_ct *ct, uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct && data, "null argument");
     ctx->cx.sync();
     HIP_CHECK(hipMemcpy(data, ct->c.d, ct->c.bytes(), hipMemcpyDeviceToHost));
@@ -278,6 +287,7 @@ int hydia_ct_device_ptr(const hydia_ct *ct, void **ptr, size_t *bytes) {
 }
 int hydia_ct_copy_to_device(hydia_ctx *ctx, const hydia_ct *ct, void *dev_dst) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct && dev_dst, "null argument");
     HIP_CHECK(hipMemcpyAsync(dev_dst, ct->c.d, ct->c.bytes(), hipMemcpyDeviceToDevice, ctx->cx.stream));
     ctx->cx.sync();
@@ -287,34 +297,46 @@ int hydia_ct_copy_to_device(hydia_ctx *ctx, const hydia_ct *ct, void *dev_dst) {
 int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
                          double scale, hydia_ct **out) {
     API_BEGIN
-    REQUIRE(ctx && dev_ptr && out && count >= 1, "bad argument");
+    use_device(ctx);
+    REQUIRE(ctx && dev_ptr && out, "null argument");
+    REQUIRE(count >= 1 && (n_polys == 2 || n_polys == 3) && n_limbs >= 1 && (int)n_limbs <= ctx->cx.nQ, "bad ciphertext shape");
     Ct c(&ctx->cx, (int)count, (int)n_polys, (int)n_limbs, scale);
     ctx->cx.sync();
     HIP_CHECK(hipMemcpy(c.d, dev_ptr, c.bytes(), hipMemcpyDeviceToDevice));
-    *out = wrap(std::move(c));
+    *out = wrap(ctx, std::move(c));
     return HYDIA_OK;
     API_END
 }
-void hydia_ct_free(hydia_ct *ct) { delete ct; }
+void hydia_ct_free(hydia_ct *ct) {
+    if (!ct) return;
+    hydia_ctx *owner = ct->owner;
+    delete ct;
+    if (owner && --owner->live_handles == 0 && owner->destroy_requested) delete owner;
+}
 
 // ------------------------------------------------------------------ receiver
 int hydia_encrypt_query(hydia_ctx *ctx, const double *query, const uint8_t seed[32], uint64_t nonce, hydia_ct **out) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && query && seed && out, "null argument");
-    *out = wrap(client_encrypt_query(ctx->cx, query, seed, nonce));
+    REQUIRE(nonce < HYDIA_NONCE_LIMIT, "nonce must be below 2^40");
+    *out = wrap(ctx, client_encrypt_query(ctx->cx, query, seed, nonce));
     return HYDIA_OK;
     API_END
 }
 int hydia_encrypt(hydia_ctx *ctx, const double *slots, uint32_t count, const uint8_t seed[32], uint64_t nonce0,
                   hydia_ct **out) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && slots && seed && out && count >= 1, "bad argument");
-    *out = wrap(client_encrypt(ctx->cx, slots, (int)count, seed, nonce0));
+    REQUIRE(nonce0 < HYDIA_NONCE_LIMIT && nonce0 + count <= HYDIA_NONCE_LIMIT, "nonce must be below 2^40");
+    *out = wrap(ctx, client_encrypt(ctx->cx, slots, (int)count, seed, nonce0));
     return HYDIA_OK;
     API_END
 }
 int hydia_decrypt(hydia_ctx *ctx, const hydia_ct *ct, double *out) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct && out, "null argument");
     client_decrypt(ctx->cx, ct->c, out);
     return HYDIA_OK;
@@ -323,6 +345,7 @@ int hydia_decrypt(hydia_ctx *ctx, const hydia_ct *ct, double *out) {
 /* receiver_hers.cpp:26-35 */
 int hydia_decrypt_membership(hydia_ctx *ctx, const hydia_ct *ct, int *result) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct && result, "null argument");
     std::vector<double> v((size_t)ct->c.X * ctx->cx.slots);
     client_decrypt(ctx->cx, ct->c, v.data());
@@ -333,6 +356,7 @@ int hydia_decrypt_membership(hydia_ctx *ctx, const hydia_ct *ct, int *result) {
 /* receiver_hers.cpp:37-54 */
 int hydia_decrypt_index(hydia_ctx *ctx, const hydia_ct *cts, size_t *out, size_t cap, size_t *n_out) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && cts && n_out, "null argument");
     const size_t S = ctx->cx.slots;
     std::vector<double> v((size_t)cts->c.X * S);
@@ -356,27 +380,18 @@ size_t hydia_db_num_cts(const hydia_ctx *ctx, size_t n) {
     const size_t nblk = (n + dim - 1) / dim;
     return ((nblk + per - 1) / per) * dim;
 }
-static void db_alloc(Context &cx, size_t n_vectors, size_t cts) {
-    const size_t bytes = cts * cx.db_layout().ct_bytes;
-    if (cx.d_db && cx.db_cts != cts) {
-        cx.sync();
-        HIP_CHECK(hipFree(cx.d_db));
-        cx.d_db = nullptr;
-    }
-    if (!cx.d_db && bytes) HIP_CHECK(hipMalloc((void **)&cx.d_db, bytes));
-    cx.db_cts = cts;
-    cx.db_vectors = n_vectors;
-}
 int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && n_vectors >= 1, "bad argument");
-    db_alloc(ctx->cx, n_vectors, hydia_db_num_cts(ctx, n_vectors));
+    ctx->cx.db_resize(n_vectors, hydia_db_num_cts(ctx, n_vectors));
     ctx->cx.db_kind = 5;
     return HYDIA_OK;
     API_END
 }
 int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     Context &cx = ctx->cx;
     if (!cx.d_db) return fail(HYDIA_ERR_STATE, "hydia: no database resident (call hydia_db_alloc)");
@@ -394,6 +409,7 @@ int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data) {
 }
 int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data, "null argument");
     Context &cx = ctx->cx;
     if (!cx.d_db) return fail(HYDIA_ERR_STATE, "hydia: no database resident");
@@ -409,10 +425,11 @@ int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data) {
 }
 int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && n_vectors >= 1, "bad argument");
     Context &cx = ctx->cx;
     const size_t cts = hydia_db_num_cts(ctx, n_vectors);
-    db_alloc(cx, n_vectors, cts);
+    cx.db_resize(n_vectors, cts);
     const size_t chunk = (size_t)cx.prm.dim, e = (size_t)2 * cx.nQ * cx.N;
     u64 *tmp = cx.pool.get(chunk * e * sizeof(u64));
     for (size_t t0 = 0; t0 < cts; t0 += chunk) {
@@ -428,20 +445,33 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
 }
 int hydia_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && db && seed && n >= 1, "bad argument");
     Context &cx = ctx->cx;
-    db_alloc(cx, n, hydia_db_num_cts(ctx, n));
+    cx.db_resize(n, hydia_db_num_cts(ctx, n));
     client_enroll(cx, db, n, seed);
+    cx.db_kind = 5;
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && db && seed && n >= 1, "bad argument");
+    Context &cx = ctx->cx;
+    cx.db_resize(n, hydia_db_num_cts(ctx, n));
+    client_enroll(cx, db, n, seed, first_block);
     cx.db_kind = 5;
     return HYDIA_OK;
     API_END
 }
 int hydia_hers_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && db && seed && n >= 1, "bad argument");
     Context &cx = ctx->cx;
     const size_t G = (n + cx.slots - 1) / cx.slots;  // enroller_hers.cpp:59-60
-    db_alloc(cx, n, G * cx.prm.dim);
+    cx.db_resize(n, G * cx.prm.dim);
     client_hers_enroll(cx, db, n, seed);
     cx.db_kind = 4;
     return HYDIA_OK;
@@ -449,8 +479,26 @@ int hydia_hers_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t see
 }
 int hydia_hers_encrypt_query(hydia_ctx *ctx, const double *query, const uint8_t seed[32], uint64_t nonce0, hydia_ct **out) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && query && seed && out, "null argument");
-    *out = wrap(client_hers_encrypt_query(ctx->cx, query, seed, nonce0));
+    REQUIRE(nonce0 < HYDIA_NONCE_LIMIT && nonce0 + ctx->cx.prm.dim <= HYDIA_NONCE_LIMIT, "nonce must be below 2^40");
+    *out = wrap(ctx, client_hers_encrypt_query(ctx->cx, query, seed, nonce0));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_save(hydia_ctx *ctx, const char *path) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && path, "null argument");
+    ctx->cx.db_save(path);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_db_load(hydia_ctx *ctx, const char *path) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && path, "null argument");
+    ctx->cx.db_load(path);
     return HYDIA_OK;
     API_END
 }
@@ -465,8 +513,9 @@ int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_
 // ------------------------------------------------------------------ sender
 #define SENDER_CALL(expr)                                 \
     API_BEGIN                                             \
+    use_device(ctx);                                      \
     REQUIRE(ctx && query && out, "null argument");        \
-    *out = wrap(expr);                                    \
+    *out = wrap(ctx, expr);                                  \
     return HYDIA_OK;                                      \
     API_END
 int hydia_rotate_query(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.rotate_query(query->c)) }
@@ -477,6 +526,31 @@ int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *query, double delta,
     SENDER_CALL(ctx->cx.chebyshev_compare(query->c, delta, (int)sign_depth))
 }
 int hydia_sum_and_evalsum(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.sum_and_evalsum(query->c)) }
+int hydia_add_many(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.add_many(query->c)) }
+int hydia_eval_sum(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.eval_sum(query->c)) }
+int hydia_ct_add_raw(hydia_ctx *ctx, hydia_ct *acc, const void *dev_src, int src_device) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && acc && dev_src, "null argument");
+    Context &cx = ctx->cx;
+    u64 *tmp = cx.pool.get(acc->c.bytes());
+    cx.sync();
+    if (src_device < 0 || src_device == cx.device) HIP_CHECK(hipMemcpy(tmp, dev_src, acc->c.bytes(), hipMemcpyDeviceToDevice));
+    else HIP_CHECK(hipMemcpyPeer(tmp, cx.device, dev_src, src_device, acc->c.bytes()));
+    cx.add_raw_inplace(acc->c, tmp);
+    cx.sync();
+    cx.pool.put(tmp);
+    return HYDIA_OK;
+    API_END
+}
+int hydia_ct_mod_reduce(hydia_ctx *ctx, hydia_ct *ct) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && ct, "null argument");
+    ctx->cx.mod_reduce_inplace(ct->c);
+    return HYDIA_OK;
+    API_END
+}
 int hydia_hers_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.hers_similarity(query->c)) }
 int hydia_hers_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.hers_index_scenario(query->c)) }
 int hydia_hers_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.hers_membership_scenario(query->c)) }
@@ -484,6 +558,7 @@ int hydia_hers_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_
 // ------------------------------------------------------------------ primitives
 int hydia_ntt(hydia_ctx *ctx, uint64_t *data, uint32_t count, uint32_t m, int inverse) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && data && count >= 1 && (int)m < ctx->cx.nT, "bad argument");
     Context &cx = ctx->cx;
     const size_t bytes = (size_t)count * cx.N * sizeof(u64);
@@ -510,6 +585,7 @@ int hydia_eval_mult_no_relin(hydia_ctx *ctx, const hydia_ct *query, const hydia_
 }
 int hydia_relinearize(hydia_ctx *ctx, hydia_ct *ct) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct, "null argument");
     ctx->cx.relinearize(ct->c);
     return HYDIA_OK;
@@ -517,6 +593,7 @@ int hydia_relinearize(hydia_ctx *ctx, hydia_ct *ct) {
 }
 int hydia_rescale(hydia_ctx *ctx, hydia_ct *ct) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct, "null argument");
     ctx->cx.rescale(ct->c);
     return HYDIA_OK;
@@ -524,6 +601,7 @@ int hydia_rescale(hydia_ctx *ctx, hydia_ct *ct) {
 }
 int hydia_eval_add(hydia_ctx *ctx, hydia_ct *a, const hydia_ct *b) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && a && b, "null argument");
     ctx->cx.add_inplace(a->c, b->c);
     return HYDIA_OK;
@@ -531,6 +609,7 @@ int hydia_eval_add(hydia_ctx *ctx, hydia_ct *a, const hydia_ct *b) {
 }
 int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && ct && n_limbs >= 1, "bad argument");
     if ((int)n_limbs < ct->c.nl) {
         Ct v = ct->c.alias((int)n_limbs);
@@ -543,6 +622,7 @@ int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs) {
 // ------------------------------------------------------------------ measurement
 int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64_t *launches) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx && name, "null argument");
     ctx->cx.timer_collect();
     auto it = ctx->cx.timers.find(name);
@@ -553,6 +633,7 @@ int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64
 }
 int hydia_kernel_time_reset(hydia_ctx *ctx) {
     API_BEGIN
+    use_device(ctx);
     REQUIRE(ctx, "null ctx");
     ctx->cx.timer_collect();
     ctx->cx.timers.clear();

@@ -79,6 +79,7 @@ void client_keygen(Context &cx, const uint8_t seed[32]) {
     const int N = cx.N, nT = cx.nT, nQ = cx.nQ;
     const ChaChaKey key = make_key(seed);
     const LimbSel all = cx.sel_range(0, nT), qsel = cx.sel_q(nQ);
+    if (cx.keys_borrowed) throw StateError("hydia: this context borrows its keys from another context (re-key the owner)");
     if (!cx.d_sk) HIP_CHECK(hipMalloc((void **)&cx.d_sk, sizeof(u64) * (size_t)nT * N));
     if (!cx.d_pk) HIP_CHECK(hipMalloc((void **)&cx.d_pk, sizeof(u64) * (size_t)2 * nQ * N));
     int *s32 = (int *)cx.pool.get(sizeof(int) * (size_t)N);
@@ -114,7 +115,7 @@ void client_keygen(Context &cx, const uint8_t seed[32]) {
 
 // encode + encrypt X slot vectors that already sit in HBM; writes [X][2][nQ][N] at dst
 static void encrypt_device(Context &cx, const double *d_slots, int X, const ChaChaKey &key, u64 nonce0, u64 *dst) {
-    if (!cx.d_pk) throw std::runtime_error("hydia: public key not loaded");
+    if (!cx.d_pk) throw StateError("hydia: public key not loaded");
     ensure_embedding_tables(cx);
     const int N = cx.N, nQ = cx.nQ, Nh = cx.slots;
     const LimbSel qsel = cx.sel_q(nQ);
@@ -170,7 +171,7 @@ Ct client_encrypt_query(Context &cx, const double *query, const uint8_t seed[32]
 }
 
 void client_decrypt(Context &cx, const Ct &ct, double *out) {
-    if (!cx.d_sk) throw std::runtime_error("hydia: secret key not loaded");
+    if (!cx.d_sk) throw StateError("hydia: secret key not loaded");
     ensure_embedding_tables(cx);
     const int N = cx.N, Nh = cx.slots, X = ct.X, nu = ct.nl < 2 ? ct.nl : 2;
     u64 *t = cx.pool.get(sizeof(u64) * (size_t)X * nu * N);
@@ -191,7 +192,7 @@ void client_decrypt(Context &cx, const Ct &ct, double *out) {
 #define HY_DB_NONCE_BASE (1ull << 36)
 // DiagonalEnroller::serializeDB: normalise IN PLACE (enroller_diag.cpp:32-35), then per group of `slots` rows: pack the
 // generalised diagonals (:37-45) and encrypt the vector_dim slot vectors (:48-52) into the resident HBM layout.
-void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]) {
+void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32], size_t first_block) {
     const int dim = cx.prm.dim, Nh = cx.slots;
     for (long long v = 0; v < (long long)n; v++) normalize(db + (size_t)v * dim, dim);
     const ChaChaKey key = make_key(seed);
@@ -205,7 +206,7 @@ void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32]) {
         if (rows)
             HIP_CHECK(hipMemcpyAsync(d_rows, db + first * dim, sizeof(double) * rows * dim, hipMemcpyHostToDevice, cx.stream));
         hc::diag_pack(cx.stream, d_rows, (long long)rows, dim, Nh, d_slots);
-        encrypt_device(cx, d_slots, dim, key, HY_DB_NONCE_BASE + g * dim, d_cts);
+        encrypt_device(cx, d_slots, dim, key, HY_DB_NONCE_BASE + (first_block + g) * dim, d_cts);
         cx.db_store(g * dim, d_cts, dim);
     }
     cx.sync();

@@ -6,6 +6,7 @@
 // framework's own deterministic specification (DESIGN.md §"RNS parameters"); tests check it against the oracle.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -357,8 +358,10 @@ Context::~Context() {
     pool.trim();
     rot_keys[0] = relin_key;
     for (auto &kv : rot_keys)
-        for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
-            if (p) (void)hipFree(p);
+        if (!kv.second.borrowed)
+            for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
+                if (p) (void)hipFree(p);
+    if (keys_borrowed) d_rotpack = nullptr, d_sk = nullptr, d_pk = nullptr;
     for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp, (void *)d_twf, (void *)d_itwf,
                     (void *)d_rotptrs, (void *)d_rotpack,
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
@@ -416,7 +419,33 @@ u64 Context::galois_elt(int rot) const {
 }
 
 // ------------------------------------------------------------------ evaluation keys
+void Context::adopt_keys(Context &src) {
+    if (&src == this) return;
+    if (src.device != device) throw std::runtime_error("hydia: keys can only be shared between contexts on the same GPU");
+    if (src.nT != nT || src.N != N || src.prm.dnum != prm.dnum || src.prm.dim != prm.dim || src.q != q)
+        throw std::runtime_error("hydia: keys can only be shared between contexts with identical parameters");
+    if (relin_key.d || !rot_keys.empty() || d_sk || d_pk) throw StateError("hydia: this context already holds keys of its own");
+    src.build_rotptrs();  // packed shadow of rotations 1..dim-1 (throws StateError when a rotation key is missing)
+    src.sync_all();
+    relin_key = src.relin_key;
+    relin_key.borrowed = true;
+    for (auto &kv : src.rot_keys) {
+        EvalKey k = kv.second;
+        k.borrowed = true;
+        rot_keys[kv.first] = k;
+    }
+    d_sk = src.d_sk;
+    d_pk = src.d_pk;
+    d_rotpack = src.d_rotpack;
+    rotptrs_packed = src.rotptrs_packed;
+    keys_borrowed = true;
+    HIP_CHECK(hipMemcpy((void *)d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)prm.dim, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpy(d_rotgalois, src.d_rotgalois, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpy(d_rotginv, src.d_rotginv, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice));
+    rotptrs_valid = true;
+}
 u64 *Context::eval_key_storage(int rot) {
+    if (keys_borrowed) throw StateError("hydia: this context borrows its keys from another context (re-key the owner)");
     EvalKey &k = rot == 0 ? relin_key : rot_keys[rot];
     if (!k.d) {
         const size_t bytes = (size_t)prm.dnum * 2 * nT * N * sizeof(u64);
@@ -433,8 +462,10 @@ u64 *Context::eval_key_storage(int rot) {
         }
         HIP_CHECK(hipMemcpy((void *)k.d_cell, &self, sizeof(u64 *), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(k.d_gal, g, 2 * sizeof(unsigned), hipMemcpyHostToDevice));
-        rotptrs_valid = false;
     }
+    // every caller is about to WRITE this key (import, key generation, random fill): loop A's pointer table and its packed
+    // shadow of rotations 1..dim-1 are rebuilt from the new contents before the next query
+    if (rot >= 1 && rot < prm.dim) rotptrs_valid = false;
     return k.d;
 }
 void Context::load_eval_key(int rot, const u64 *host) {
@@ -444,6 +475,80 @@ void Context::load_eval_key(int rot, const u64 *host) {
 }
 
 // ------------------------------------------------------------------ resident database
+void Context::db_resize(size_t n_vectors, size_t cts) {
+    const size_t bytes = cts * db_layout().ct_bytes;
+    if (d_db && db_cts != cts) {
+        sync_all();
+        HIP_CHECK(hipFree(d_db));
+        d_db = nullptr;
+    }
+    if (!d_db && bytes) HIP_CHECK(hipMalloc((void **)&d_db, bytes));
+    db_cts = cts;
+    db_vectors = n_vectors;
+}
+namespace {
+struct DbFileHeader {
+    char magic[8];  // "HYDIADB1"
+    uint32_t logN, nQ, dim, packed, kind, reserved;
+    uint64_t n_vectors, n_cts, ct_bytes;
+    uint64_t moduli[HY_MAX_MODS];
+};
+const size_t DB_IO_CHUNK = (size_t)64 << 20;
+struct FileCloser {
+    FILE *f;
+    ~FileCloser() {
+        if (f) fclose(f);
+    }
+};
+struct PinnedBuf {
+    void *p = nullptr;
+    explicit PinnedBuf(size_t n) { HIP_CHECK(hipHostMalloc(&p, n, hipHostMallocDefault)); }
+    ~PinnedBuf() { (void)hipHostFree(p); }
+};
+}  // namespace
+void Context::db_save(const char *path) {
+    if (!d_db || db_cts == 0) throw StateError("hydia: no database resident");
+    sync_all();
+    FileCloser fc{fopen(path, "wb")};
+    if (!fc.f) throw std::runtime_error(std::string("hydia: cannot open ") + path + " for writing");
+    DbFileHeader h{};
+    memcpy(h.magic, "HYDIADB1", 8);
+    h.logN = (uint32_t)prm.logN; h.nQ = (uint32_t)nQ; h.dim = (uint32_t)prm.dim; h.packed = db_packed ? 1 : 0; h.kind = (uint32_t)db_kind;
+    h.n_vectors = db_vectors; h.n_cts = db_cts; h.ct_bytes = db_layout().ct_bytes;
+    for (int j = 0; j < nQ; j++) h.moduli[j] = q[j];
+    if (fwrite(&h, sizeof h, 1, fc.f) != 1) throw std::runtime_error("hydia: write failed (header)");
+    const size_t total = db_cts * db_layout().ct_bytes;
+    PinnedBuf buf(std::min(total, DB_IO_CHUNK));
+    for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
+        const size_t n = std::min(DB_IO_CHUNK, total - off);
+        HIP_CHECK(hipMemcpy(buf.p, d_db + off, n, hipMemcpyDeviceToHost));
+        if (fwrite(buf.p, 1, n, fc.f) != n) throw std::runtime_error("hydia: write failed (disk full?)");
+    }
+}
+void Context::db_load(const char *path) {
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f) throw std::runtime_error(std::string("hydia: cannot open ") + path);
+    DbFileHeader h{};
+    if (fread(&h, sizeof h, 1, fc.f) != 1 || memcmp(h.magic, "HYDIADB1", 8) != 0) throw std::runtime_error("hydia: not a hydia database file");
+    if ((int)h.logN != prm.logN || (int)h.nQ != nQ || (int)h.dim != prm.dim) throw std::runtime_error("hydia: database file was written for other parameters");
+    for (int j = 0; j < nQ; j++)
+        if (h.moduli[j] != q[j]) throw std::runtime_error("hydia: database file was written on another prime chain");
+    if ((h.packed != 0) != db_packed || h.ct_bytes != db_layout().ct_bytes)
+        throw std::runtime_error("hydia: database file layout (48-bit packed / 8-byte) differs from this context's");
+    if (h.kind != 4 && h.kind != 5) throw std::runtime_error("hydia: database file has an unknown packing kind");
+    db_resize(h.n_vectors, h.n_cts);
+    const size_t total = db_cts * db_layout().ct_bytes;
+    PinnedBuf buf(std::min(total, DB_IO_CHUNK));
+    for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
+        const size_t n = std::min(DB_IO_CHUNK, total - off);
+        if (fread(buf.p, 1, n, fc.f) != n) {
+            db_kind = 0;
+            throw std::runtime_error("hydia: database file is truncated");
+        }
+        HIP_CHECK(hipMemcpy(d_db + off, buf.p, n, hipMemcpyHostToDevice));
+    }
+    db_kind = (int)h.kind;
+}
 void Context::db_store(size_t t0, const u64 *d_plain, int X) {
     hk::db_pack(stream, N, nQ, d_plain, d_db + t0 * db_layout().ct_bytes, X, db_packed ? 1 : 0);
 }

@@ -170,18 +170,18 @@ void Context::build_rotptrs() {
     for (int j = 1; j < nQ; j++)
         if (q[j] >> 48) pack = false;
     const size_t kb = hk::key_packed_bytes(N, nQ, nT, prm.dnum);
-    if (d_rotpack) {
-        HIP_CHECK(hipStreamSynchronize(stream));
+    sync_all();  // a re-key must not repack the shadow under a query still in flight
+    if (d_rotpack && !pack) {
         (void)hipFree(d_rotpack);
         d_rotpack = nullptr;
     }
-    if (pack && hipMalloc((void **)&d_rotpack, kb * (size_t)(prm.dim - 1)) != hipSuccess) {
+    if (pack && !d_rotpack && hipMalloc((void **)&d_rotpack, kb * (size_t)(prm.dim - 1)) != hipSuccess) {
         d_rotpack = nullptr;  // not enough HBM for the shadow: loop A reads the plain keys
         pack = false;
     }
     for (int i = 1; i < prm.dim; i++) {
         auto it = rot_keys.find(i);
-        if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(i) + " not loaded");
+        if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(i) + " not loaded");
         if (pack) {
             hk::key_pack(stream, N, nQ, nT, prm.dnum, it->second.d, d_rotpack + kb * (size_t)(i - 1));
             ptrs[i] = reinterpret_cast<const u64 *>(d_rotpack + kb * (size_t)(i - 1));
@@ -204,7 +204,7 @@ void Context::build_rotptrs() {
 // RelinearizeInPlace (sender_diag.cpp:79)
 void Context::relinearize(Ct &c, bool dbl) {
     if (c.npoly != 3) return;
-    if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
+    if (!relin_key.d) throw StateError("hydia: relinearisation key not loaded");
     const int nl = c.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
@@ -273,7 +273,7 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
         }
         return;
     }
-    if (!relin_key.d) throw std::runtime_error("hydia: relinearisation key not loaded");
+    if (!relin_key.d) throw StateError("hydia: relinearisation key not loaded");
     if (sub && (sub->X != c.X || sub->npoly != 2 || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
@@ -472,7 +472,7 @@ Ct Context::mult(const Ct &a, const Ct &b) {
 // EvalRotate on every ciphertext of the batch (EvalSum's step, sender_diag.cpp:47)
 Ct Context::rotate(const Ct &a, int rot) {
     auto it = rot_keys.find(rot);
-    if (it == rot_keys.end()) throw std::runtime_error("hydia: rotation key " + std::to_string(rot) + " not loaded");
+    if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(rot) + " not loaded");
     const int nl = a.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = a.X;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(a.d + a.poly_elems(), a.ct_elems(), X, nl, dig);
@@ -804,8 +804,8 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
 }
 // the degree-2 accumulators of loop B for all resident blocks (computeSimilarity without its relinearise / rescale tail)
 Ct Context::similarity_accumulate(const Ct &qc) {
-    if (!d_db || db_cts == 0 || db_kind != 5) throw std::runtime_error("hydia: no database resident (diagonal packing)");
-    if (qc.nl != nQ) throw std::runtime_error("hydia: query must be a fresh (level 0) ciphertext");
+    if (!d_db || db_cts == 0 || db_kind != 5) throw StateError("hydia: no database resident (diagonal packing)");
+    if (qc.nl != nQ) throw StateError("hydia: query must be a fresh (level 0) ciphertext");
     const int dim = prm.dim;
     const int G = (int)(db_cts / dim);
     Ct rot = rotate_query(qc);
@@ -825,7 +825,8 @@ Ct Context::membership_scenario(const Ct &qc) {
     Ct s = index_scenario(qc);
     return sum_and_evalsum(s);
 }
-Ct Context::sum_and_evalsum(const Ct &s) {
+// EvalAddManyInPlace (sender_diag.cpp:46): the batch summed into its first element's shape, one modular add per block
+Ct Context::add_many(const Ct &s) {
     Ct first = s.alias(s.nl);
     first.X = 1;
     Ct m = clone(first);
@@ -835,19 +836,38 @@ Ct Context::sum_and_evalsum(const Ct &s) {
         v.d = s.d + (size_t)g * s.ct_elems();
         add_inplace(m, v);
     }
+    return m;
+}
+// EvalSum(ct, batchSize) (sender_diag.cpp:47): log2(slots) rotate-and-add steps
+Ct Context::eval_sum(const Ct &a) {
+    Ct m = clone(a);
     for (int r = 1; r < slots; r <<= 1) {
         Ct t = rotate(m, r);
         add_inplace(m, t);
     }
     return m;
 }
+Ct Context::sum_and_evalsum(const Ct &s) {
+    Ct m = add_many(s);
+    for (int r = 1; r < slots; r <<= 1) {
+        Ct t = rotate(m, r);
+        add_inplace(m, t);
+    }
+    return m;
+}
+// Cross-shard membership reduction: partial sums of the shards are added as plain 64-bit integers (what an RCCL
+// all-reduce(SUM) on int64 does: at most 8 residues below 2^60 cannot overflow) and reduced once.
+void Context::add_raw_inplace(Ct &a, const u64 *other) {
+    hk::add_raw(stream, d_mod, N, a.d, other, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride, a.nl, a.lstride);
+}
+void Context::mod_reduce_inplace(Ct &a) { hk::mod_reduce(stream, d_mod, N, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride); }
 
 // ------------------------------------------------------------------ HERS sender (approach 4)
 // HersSender::computeSimilarity / computeSimilarityHelper (/root/reference/src/sender/sender_hers.cpp:13-87): per block the
 // dim products EvalMultNoRelin(query_i, db[m][i]) are relinearised and rescaled ONE BY ONE ("to match HERS paper approach",
 // :73-75) and then summed — run here as one batch of dim ciphertexts per block.
 Ct Context::hers_similarity(const Ct &qc) {
-    if (!d_db || db_cts == 0 || db_kind != 4) throw std::runtime_error("hydia: no database resident (HERS column packing)");
+    if (!d_db || db_cts == 0 || db_kind != 4) throw StateError("hydia: no database resident (HERS column packing)");
     const int dim = prm.dim;
     if (qc.X != dim || qc.npoly != 2 || qc.nl != nQ || !qc.compact())
         throw std::runtime_error("hydia: HERS query must be vector_dim fresh ciphertexts");

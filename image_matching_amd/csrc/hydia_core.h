@@ -12,11 +12,21 @@
 
 #include "kernels.h"
 
+namespace hydia {
+// error classes of the C-ABI (include/hydia.h hydia_status): the boundary classifies by TYPE, never by message text
+struct DeviceError : std::runtime_error {  // a HIP call failed -> HYDIA_ERR_DEVICE
+    using std::runtime_error::runtime_error;
+};
+struct StateError : std::runtime_error {   // missing key / database / wrong level -> HYDIA_ERR_STATE
+    using std::runtime_error::runtime_error;
+};
+}  // namespace hydia
+
 #define HIP_CHECK(expr)                                                                                   \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \
         if (_e != hipSuccess)                                                                             \
-            throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));           \
+            throw hydia::DeviceError(std::string(#expr) + " failed: " + hipGetErrorString(_e));           \
     } while (0)
 
 namespace hydia {
@@ -112,6 +122,7 @@ struct Context : HostParams {
         u64 *d = nullptr;
         const u64 **d_cell = nullptr;
         unsigned *d_gal = nullptr;   // [0] = Galois element g, [1] = g^{-1} mod 2N
+        bool borrowed = false;       // storage belongs to another context on the same GPU (adopt_keys)
     };
     EvalKey relin_key;
     std::map<int, EvalKey> rot_keys;
@@ -121,6 +132,11 @@ struct Context : HostParams {
     bool rotptrs_valid = false, rotptrs_packed = false;
     unsigned char *d_rotpack = nullptr;  // packed shadow of rotation keys 1..dim-1 (45/46-bit limbs as 6-byte residues), loop A only
     bool rot_packed = true;              // HYDIA_KEYS_UNPACKED turns the shadow off
+    // Contexts on the SAME GPU (shards of one database that share a device) can use one resident copy of the keys: this
+    // context borrows every key buffer of `src` (relin, rotations, packed shadow, pk, sk); `src` must outlive it and must
+    // not be re-keyed while borrowers exist.
+    void adopt_keys(Context &src);
+    bool keys_borrowed = false;
     void load_eval_key(int rot /* 0 = relinearisation */, const u64 *host);
     u64 *eval_key_storage(int rot);    // allocates (or returns) the HBM buffer of key `rot`
     u64 *d_sk = nullptr;               // [nT][N] (receiver side only)
@@ -135,6 +151,11 @@ struct Context : HostParams {
     int db_kind = 0;   // 0 none, 5 diagonal packing (HyDia, approach 5), 4 column packing (HERS, approach 4)
     bool db_packed = true;
     DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }
+    void db_resize(size_t n_vectors, size_t cts);         // (re)allocates the resident layout for `cts` ciphertexts
+    // persistence of the resident database (own streaming format: header + the resident layout verbatim, so a restart does not
+    // re-enrol from plaintext; the reference keeps serial/db_diagonal/index<t>.bin, enroller_diag.cpp:158-166)
+    void db_save(const char *path);
+    void db_load(const char *path);
     void db_store(size_t t0, const u64 *d_plain, int X);  // [X][2][nQ][N] device residues -> ciphertexts t0..t0+X-1
     void db_fetch(size_t t0, u64 *d_plain, int X);
 
@@ -202,6 +223,10 @@ struct Context : HostParams {
     Ct index_scenario(const Ct &q);
     Ct membership_scenario(const Ct &q);
     Ct sum_and_evalsum(const Ct &s);  // EvalAddMany over the batch + EvalSum over all slots
+    Ct add_many(const Ct &s);         // EvalAddManyInPlace alone (the per-shard part of a sharded membership query)
+    Ct eval_sum(const Ct &a);         // EvalSum alone
+    void add_raw_inplace(Ct &a, const u64 *other /* compact, same shape, this device */);  // integer sum, no reduction
+    void mod_reduce_inplace(Ct &a);   // every 64-bit value -> canonical residue of its limb
     // ---- HERS sender (approach 4, src/sender/sender_hers.cpp): q = dim query ciphertexts
     Ct hers_similarity(const Ct &q);
     Ct hers_index_scenario(const Ct &q);

@@ -131,6 +131,10 @@ void add(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64
          int b_ls, int o_ls);
 void sub(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
          int b_ls, int o_ls);
+// cross-shard membership reduction (multi-GPU): o = a + b as plain 64-bit integers, then every value -> its canonical residue
+void add_raw(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
+             int b_ls, int o_ls);
+void mod_reduce(hipStream_t st, const ModC *mod, int N, u64 *a, int XP, const LimbSel &sel, int a_ls);
 void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, int XP, const LimbSel &sel,
                 const ScaleSel &c, int a_ls, int o_ls);  // o = a * c[slot]
 void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,

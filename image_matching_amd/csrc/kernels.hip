@@ -126,9 +126,18 @@ __global__ __launch_bounds__(256) void k_addsub(const ModC *__restrict__ mod, in
     const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a + (size_t)xp * a_ls * N + i);
     const ulonglong2 vb = *reinterpret_cast<const ulonglong2 *>(b + (size_t)xp * b_ls * N + i);
     ulonglong2 r;
-    r.x = OP == 0 ? addmod(va.x, vb.x, q) : submod(va.x, vb.x, q);
-    r.y = OP == 0 ? addmod(va.y, vb.y, q) : submod(va.y, vb.y, q);
+    // OP 2: plain integer sum (the cross-shard membership reduction keeps residues unreduced until k_mod_reduce)
+    r.x = OP == 0 ? addmod(va.x, vb.x, q) : OP == 1 ? submod(va.x, vb.x, q) : va.x + vb.x;
+    r.y = OP == 0 ? addmod(va.y, vb.y, q) : OP == 1 ? submod(va.y, vb.y, q) : va.y + vb.y;
     *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * o_ls * N + i) = r;
+}
+// any 64-bit value -> canonical residue of its limb (after an integer all-reduce of at most 8 residues < 2^60)
+__global__ __launch_bounds__(256) void k_mod_reduce(const ModC *__restrict__ mod, int N, u64 *a, LimbSel sel, int a_ls) {
+    const int y = blockIdx.y, xp = y / sel.n, slot = y - xp * sel.n;
+    const ModC M = mod[sel.mod[slot]];
+    u64 *p = a + (size_t)xp * a_ls * N + (size_t)slot * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+    *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(reduce64(v.x, M), reduce64(v.y, M));
 }
 __global__ __launch_bounds__(256) void k_mul_scalar(const ModC *__restrict__ mod, int N, const u64 *__restrict__ a,
                                                     u64 *__restrict__ o, LimbSel sel, ScaleSel c, int a_ls, int o_ls) {
@@ -645,6 +654,13 @@ void add(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64
 void sub(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
          int b_ls, int o_ls) {
     hipLaunchKernelGGL(k_addsub<1>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
+}
+void add_raw(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
+             int b_ls, int o_ls) {
+    hipLaunchKernelGGL(k_addsub<2>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
+}
+void mod_reduce(hipStream_t st, const ModC *mod, int N, u64 *a, int XP, const LimbSel &sel, int a_ls) {
+    hipLaunchKernelGGL(k_mod_reduce, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, sel, a_ls);
 }
 void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, int XP, const LimbSel &sel,
                 const ScaleSel &c, int a_ls, int o_ls) {

@@ -92,6 +92,8 @@ def load_library():
         "hydia_db_import_ct": (i32, [vp, sz, vp]),
         "hydia_db_export_ct": (i32, [vp, sz, vp]),
         "hydia_db_fill_random": (i32, [vp, sz, u64]),
+        "hydia_db_save": (i32, [vp, C.c_char_p]),
+        "hydia_db_load": (i32, [vp, C.c_char_p]),
         "hydia_db_stats": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "hydia_rotate_query": (i32, [vp, vp, pp]),
         "hydia_compute_similarity": (i32, [vp, vp, pp]),
@@ -99,6 +101,23 @@ def load_library():
         "hydia_membership_scenario": (i32, [vp, vp, pp]),
         "hydia_chebyshev_compare": (i32, [vp, vp, dbl, sz, pp]),
         "hydia_sum_and_evalsum": (i32, [vp, vp, pp]),
+        "hydia_add_many": (i32, [vp, vp, pp]),
+        "hydia_eval_sum": (i32, [vp, vp, pp]),
+        "hydia_ct_add_raw": (i32, [vp, vp, vp, i32]),
+        "hydia_ct_mod_reduce": (i32, [vp, vp]),
+        "hydia_db_enroll_shard": (i32, [vp, vp, sz, vp, sz]),
+        "hydia_random_seed": (i32, [vp]),
+        "hydia_shard_blocks": (None, [sz, u32, u32, C.POINTER(sz), C.POINTER(sz)]),
+        "hydia_group_create": (i32, [C.POINTER(_Params), C.POINTER(i32), u32, pp]),
+        "hydia_group_destroy": (None, [vp]),
+        "hydia_group_size": (u32, [vp]),
+        "hydia_group_ctx": (vp, [vp, u32]),
+        "hydia_group_keygen": (i32, [vp, vp]),
+        "hydia_group_db_enroll": (i32, [vp, vp, sz, vp]),
+        "hydia_group_shard_range": (i32, [vp, u32, C.POINTER(sz), C.POINTER(sz)]),
+        "hydia_group_compute_similarity": (i32, [vp, vp, pp]),
+        "hydia_group_index_scenario": (i32, [vp, vp, pp]),
+        "hydia_group_membership_scenario": (i32, [vp, vp, pp]),
         "hydia_hers_db_enroll": (i32, [vp, vp, sz, vp]),
         "hydia_hers_encrypt_query": (i32, [vp, vp, vp, u64, pp]),
         "hydia_hers_compute_similarity": (i32, [vp, vp, pp]),
@@ -133,6 +152,10 @@ def _p(a):
 
 
 def _seed(x):
+    """32-byte sampler key.  None = fresh OS entropy (what every role method defaults to: the reference seeds OpenFHE's PRNG
+    from the OS); an int or 32 bytes = a reproducible key for tests — a (seed, nonce) pair must never encrypt two plaintexts."""
+    if x is None:
+        return np.frombuffer(os.urandom(32), dtype=np.uint8).copy()
     if isinstance(x, (bytes, bytearray)):
         b = bytes(x)
         assert len(b) == 32
@@ -174,7 +197,9 @@ class Ciphertext:
         self.cc, self.h = cc, h
 
     def __del__(self):
-        if getattr(self, "h", None) and self.cc.h:
+        # a handle pins its context inside the library (hydia_ctx_destroy defers until the last handle is gone), so it can
+        # always be released, also after Context.close()
+        if getattr(self, "h", None):
             self.cc.L.hydia_ct_free(self.h)
             self.h = None
 
@@ -220,6 +245,10 @@ class Context:
             _chk(self.L.hydia_ctx_create_custom(C.byref(self.params), _p(moduli), None if roots is None else _p(roots),
                                                 len(moduli) - n_p, n_p, device, C.byref(h)))
         self.h = h
+        self.owned = True
+        self._read_info()
+
+    def _read_info(self):
         info = _Info()
         _chk(self.L.hydia_get_info(self.h, C.byref(info)))
         self.info = info
@@ -230,10 +259,18 @@ class Context:
         self.roots = np.zeros(self.nT, dtype=np.uint64)
         _chk(self.L.hydia_get_moduli(self.h, _p(self.moduli), _p(self.roots)))
 
+    @classmethod
+    def _borrowed(cls, L, params, h):
+        """A view of a context owned by a shard group (never destroyed through this object)."""
+        self = cls.__new__(cls)
+        self.L, self.params, self.h, self.owned = L, params, C.c_void_p(h), False
+        self._read_info()
+        return self
+
     def close(self):
-        if self.h:
+        if self.h and getattr(self, "owned", True):
             self.L.hydia_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -245,7 +282,7 @@ class Context:
         _chk(self.L.hydia_sync(self.h))
 
     # ---- keys
-    def keygen(self, seed):
+    def keygen(self, seed=None):
         _chk(self.L.hydia_keygen(self.h, _p(_seed(seed))))
 
     def import_eval_key(self, rot, data):
@@ -305,7 +342,7 @@ class Context:
         _chk(fn(self.h, *args, C.byref(h)))
         return Ciphertext(self, h)
 
-    def encrypt(self, slots, seed, nonce0=0):
+    def encrypt(self, slots, seed=None, nonce0=0):
         slots = np.ascontiguousarray(slots, dtype=np.float64)
         if slots.ndim == 1:
             slots = slots[None]
@@ -352,6 +389,20 @@ class Context:
     def sum_and_evalsum(self, ct):
         return self._out(self.L.hydia_sum_and_evalsum, ct.h)
 
+    def add_many(self, ct):
+        """EvalAddManyInPlace (sender_diag.cpp:46): the batch summed into one ciphertext."""
+        return self._out(self.L.hydia_add_many, ct.h)
+
+    def eval_sum(self, ct):
+        """EvalSum(ct, batchSize) (sender_diag.cpp:47)."""
+        return self._out(self.L.hydia_eval_sum, ct.h)
+
+    def ct_add_raw(self, acc, dev_ptr, src_device=-1):
+        _chk(self.L.hydia_ct_add_raw(self.h, acc.h, C.c_void_p(dev_ptr), src_device))
+
+    def ct_mod_reduce(self, ct):
+        _chk(self.L.hydia_ct_mod_reduce(self.h, ct.h))
+
     # ---- database
     def db_num_cts(self, n):
         return int(self.L.hydia_db_num_cts(self.h, n))
@@ -371,6 +422,13 @@ class Context:
 
     def db_fill_random(self, n, seed=1):
         _chk(self.L.hydia_db_fill_random(self.h, n, seed))
+
+    def db_save(self, path):
+        """write the resident database (packed layout) to `path` — restart without re-enrolling"""
+        _chk(self.L.hydia_db_save(self.h, str(path).encode()))
+
+    def db_load(self, path):
+        _chk(self.L.hydia_db_load(self.h, str(path).encode()))
 
     def db_stats(self):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
@@ -398,12 +456,13 @@ class DiagonalEnroller:
     def __init__(self, cc, num_vectors):
         self.cc, self.numVectors = cc, num_vectors
 
-    def serializeDB(self, database, seed=0):
+    def serializeDB(self, database, seed=None, first_block=0):
         """DiagonalEnroller::serializeDB (src/enroller/enroller_diag.cpp:12-53).  Normalises `database` IN PLACE like
-        the reference; the ciphertexts go straight into HBM instead of serial/db_diagonal/index<t>.bin."""
+        the reference; the ciphertexts go straight into HBM instead of serial/db_diagonal/index<t>.bin.  first_block > 0:
+        `database` is one shard (a contiguous range of 16384-vector blocks) of a larger database."""
         assert database.dtype == np.float64 and database.flags.c_contiguous
         assert database.shape == (self.numVectors, self.cc.dim)
-        _chk(self.cc.L.hydia_db_enroll(self.cc.h, _p(database), self.numVectors, _p(_seed(seed))))
+        _chk(self.cc.L.hydia_db_enroll_shard(self.cc.h, _p(database), self.numVectors, _p(_seed(seed)), first_block))
 
 
 class DiagonalReceiver:
@@ -412,7 +471,7 @@ class DiagonalReceiver:
     def __init__(self, cc, num_vectors):
         self.cc, self.numVectors = cc, num_vectors
 
-    def encryptQuery(self, query, seed=0, nonce=1):
+    def encryptQuery(self, query, seed=None, nonce=1):
         query = np.ascontiguousarray(query, dtype=np.float64)
         assert query.shape == (self.cc.dim,)
         return self.cc._out(self.cc.L.hydia_encrypt_query, _p(query), _p(_seed(seed)), nonce)
@@ -454,7 +513,7 @@ class HersEnroller:
     def __init__(self, cc, num_vectors):
         self.cc, self.numVectors = cc, num_vectors
 
-    def serializeDB(self, database, seed=0):
+    def serializeDB(self, database, seed=None):
         """HersEnroller::serializeDB (src/enroller/enroller_hers.cpp:40-93): index-batched packing, normalises in place."""
         assert database.dtype == np.float64 and database.flags.c_contiguous
         assert database.shape == (self.numVectors, self.cc.dim)
@@ -464,7 +523,7 @@ class HersEnroller:
 class HersReceiver(DiagonalReceiver):
     """HersReceiver::encryptQuery (src/receiver/receiver_hers.cpp:13-24); decrypt* are the shared ones (:26-54)."""
 
-    def encryptQuery(self, query, seed=0, nonce=1000):
+    def encryptQuery(self, query, seed=None, nonce=1000):
         query = np.ascontiguousarray(query, dtype=np.float64)
         assert query.shape == (self.cc.dim,)
         return self.cc._out(self.cc.L.hydia_hers_encrypt_query, _p(query), _p(_seed(seed)), nonce)

@@ -1,17 +1,35 @@
-"""Row-block sharding of the encrypted database across the GPUs of one node, and the result gather.
+"""The sharded DiagonalSender: one encrypted database cut by 16384-vector row-blocks over the GPUs of a node.
 
-The reference processes the 16384-vector blocks of the database in a plain serial loop
-(/root/reference/src/sender/sender_diag.cpp:28-30); blocks are independent, so rank r owns a contiguous range of
-blocks, runs its own mat-vec, and the only exchange is the gather of result ciphertexts to rank 0 (RCCL over xGMI:
-backend "nccl" on ROCm; "gloo" in the CPU tests).  torch is used for the collective only.
+The reference walks the blocks in a plain serial loop (/root/reference/src/sender/sender_diag.cpp:28-30); blocks share
+nothing but the rotated queries, so shard r owns the contiguous block range `shard_blocks(G, R, r)`, holds the keys itself
+(same seed -> identical keys) and runs loop A + its own mat-vec + comparator.  Two drivers of the same steps:
+
+  ShardGroup / ShardedDiagonalSender   R contexts inside ONE process (libhydia's hydia_group_*: one host thread per shard,
+                                       peer copies between GPUs; shards may share a GPU) — what ./ImageMatching uses
+  DistDiagonalEnroller / DistDiagonalSender   one PROCESS per GPU over torch.distributed — backend "nccl" (= RCCL over xGMI)
+                                       with device buffers, or "gloo" with host staging (CPU tests, one-GPU rehearsals) —
+                                       what bench.py --gpus N uses
+
+indexScenario     = per-shard indexScenario, results gathered to rank/shard 0 in GLOBAL block order, so the receiver's
+                    j + i*batchSize (src/receiver/receiver_hers.cpp:46-49) is the database index
+membershipScenario= per-shard EvalAddMany (sender_diag.cpp:46) -> integer SUM of the partial ciphertexts across shards (at most
+                    16 residues below 2^60 fit 64 bits) -> one `mod q` -> EvalSum (:47) on rank/shard 0
+Both give the ciphertexts a single context holding the whole database would give, bit for bit (tests/test_gpu_sharding.py).
+torch is used for the collectives only.
 """
+import ctypes as C
+
+import numpy as np
+
+from . import hydia as _h
 
 
 def shard_blocks(total_blocks, world, rank):
-    """Contiguous block range [lo, hi) of `rank`: the first total_blocks % world ranks take one extra block."""
-    base, extra = divmod(total_blocks, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+    """Contiguous block range [lo, hi) of `rank`: the first total_blocks % world ranks take one extra block
+    (libhydia's hydia_shard_blocks — the rule the in-process group uses; host-only, needs no GPU)."""
+    lo, hi = C.c_size_t(), C.c_size_t()
+    _h.load_library().hydia_shard_blocks(total_blocks, world, rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def shard_vectors(n_total, slots, world, rank):
@@ -21,27 +39,204 @@ def shard_vectors(n_total, slots, world, rank):
     return min(blo * slots, n_total), min(bhi * slots, n_total)
 
 
-def global_indices(local_indices, rank_first_vector):
-    """decryptIndex returns j + i*batchSize inside a rank's shard (receiver_hers.cpp:46-49); shift to DB coordinates."""
-    return [int(i) + int(rank_first_vector) for i in local_indices]
+# ------------------------------------------------------------------ one process, R contexts
+class ShardGroup:
+    """R contexts of one process, one per entry of `devices` (a GPU may appear several times).  `ctx0` is where queries are
+    encrypted / imported and results decrypted."""
+
+    def __init__(self, devices, params=None):
+        self.L = _h.load_library()
+        self.params = params or _h.default_params()
+        devs = (C.c_int * len(devices))(*devices)
+        g = C.c_void_p()
+        _h._chk(self.L.hydia_group_create(C.byref(self.params), devs, len(devices), C.byref(g)))
+        self.g, self.world = g, len(devices)
+        self.ctx0 = _h.Context._borrowed(self.L, self.params, self.L.hydia_group_ctx(self.g, 0))
+
+    def shard_ctx(self, r):
+        return _h.Context._borrowed(self.L, self.params, self.L.hydia_group_ctx(self.g, r))
+
+    def keygen(self, seed=None):
+        _h._chk(self.L.hydia_group_keygen(self.g, _h._p(_h._seed(seed))))
+
+    def shard_range(self, r):
+        a, b = C.c_size_t(), C.c_size_t()
+        _h._chk(self.L.hydia_group_shard_range(self.g, r, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.g:
+            self.ctx0.h = None
+            self.L.hydia_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def gather_results(local, dist, rank, world, dst=0):
-    """Gather equally-shaped result tensors (torch, on the collective's device) to `dst`; returns the list there."""
-    import torch
-    if world == 1:
-        return [local]
-    out = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, out, dst=dst)
-    return out
+class ShardedDiagonalEnroller:
+    """DiagonalEnroller over a ShardGroup: each shard encrypts the rows of its own blocks (same nonces as unsharded)."""
+
+    def __init__(self, group, num_vectors):
+        self.group, self.numVectors = group, num_vectors
+
+    def serializeDB(self, database, seed=None):
+        assert database.dtype == np.float64 and database.flags.c_contiguous
+        assert database.shape == (self.numVectors, self.group.ctx0.dim)
+        _h._chk(self.group.L.hydia_group_db_enroll(self.group.g, _h._p(database), self.numVectors, _h._p(_h._seed(seed))))
 
 
-def allreduce_membership_residues(local, moduli_per_row, dist):
-    """Multi-GPU membership tail: residues are < 2^60, so an 8-way integer sum cannot overflow int64; all-reduce SUM
-    then reduce each limb row modulo its prime (SURVEY.md §5 'Distributed communication backend').
-    local: int64 tensor [polys*limbs, N]; moduli_per_row: python ints, one per row."""
-    import torch
-    dist.all_reduce(local, op=dist.ReduceOp.SUM)
-    for r, q in enumerate(moduli_per_row):
-        local[r] = torch.remainder(local[r], int(q))
-    return local
+class ShardedDiagonalSender:
+    """include/sender_diag.h:5-28 over a ShardGroup; query and results live in group.ctx0."""
+
+    def __init__(self, group, num_vectors):
+        self.group, self.numVectors = group, num_vectors
+
+    def _call(self, fn, q):
+        h = C.c_void_p()
+        _h._chk(fn(self.group.g, q.h, C.byref(h)))
+        return _h.Ciphertext(self.group.ctx0, h)
+
+    def computeSimilarity(self, query_cipher):
+        return self._call(self.group.L.hydia_group_compute_similarity, query_cipher)
+
+    def indexScenario(self, query_cipher):
+        return self._call(self.group.L.hydia_group_index_scenario, query_cipher)
+
+    def membershipScenario(self, query_cipher):
+        return self._call(self.group.L.hydia_group_membership_scenario, query_cipher)
+
+
+# ------------------------------------------------------------------ one process per GPU (torch.distributed)
+class DistDiagonalEnroller:
+    """Rank `rank` of `world` enrols its own rows of a database of n_total vectors: `rows` are the rank's vectors
+    (shard_vectors(n_total, slots, world, rank)), encrypted with the nonces of the unsharded enrolment."""
+
+    def __init__(self, cc, n_total, rank, world):
+        self.cc, self.n_total, self.rank, self.world = cc, n_total, rank, world
+        self.first, self.last = shard_vectors(n_total, cc.slots, world, rank)
+
+    def serializeDB(self, rows, seed=None):
+        n_local = self.last - self.first
+        assert rows.shape == (n_local, self.cc.dim)
+        if n_local:
+            _h.DiagonalEnroller(self.cc, n_local).serializeDB(rows, seed=seed, first_block=self.first // self.cc.slots)
+
+
+class DistDiagonalSender:
+    """DiagonalSender whose database is sharded over the ranks of a torch.distributed group.
+
+    cc      the rank's own context (keys loaded; its shard enrolled by DistDiagonalEnroller)
+    dist    torch.distributed (initialised); staging "device" = tensors in HBM + device pointers (nccl/RCCL),
+            "host" = numpy/torch CPU tensors (gloo)
+    Every rank calls the scenario methods; rank 0 passes the query ciphertext (other ranks pass None) and receives the result
+    (other ranks get None).  make_sender(cc, n_local) builds the rank-local sender (default DiagonalSender)."""
+
+    def __init__(self, cc, n_total, dist, rank, world, staging="device", make_sender=None):
+        import torch
+        self.torch = torch
+        self.cc, self.n_total, self.dist, self.rank, self.world, self.staging = cc, n_total, dist, rank, world, staging
+        self.G = -(-n_total // cc.slots)
+        self.ranges = [shard_blocks(self.G, world, r) for r in range(world)]
+        self.lo, self.hi = self.ranges[rank]
+        self.max_blocks = max(hi - lo for lo, hi in self.ranges)
+        first, last = shard_vectors(n_total, cc.slots, world, rank)
+        self.local = (make_sender or _h.DiagonalSender)(cc, last - first) if self.hi > self.lo else None
+        self._bufs = {}
+
+    # ---- buffers: int64 tensors that mirror [count][poly][limb][N] residues
+    def _buf(self, key, n):
+        b = self._bufs.get(key)
+        if b is None or b.numel() != n:
+            b = self.torch.zeros(n, dtype=self.torch.int64, device="cuda" if self.staging == "device" else "cpu")
+            self._bufs[key] = b
+        return b
+
+    def _fill(self, buf, ct):
+        """copy a ciphertext batch into the head of `buf`"""
+        if self.staging == "device":
+            ct.copy_to_device(buf.data_ptr())
+        else:
+            a = ct.export().reshape(-1).view(np.int64)
+            buf[:a.size] = self.torch.from_numpy(a)
+
+    def _to_ct(self, t, count, npoly, nl, scale):
+        if self.staging == "device":
+            t = t.contiguous()
+            self.torch.cuda.current_stream().synchronize()  # the collective / cat that produced `t` ran on torch's stream
+            return self.cc.ct_from_device(t.data_ptr(), count, npoly, nl, scale)
+        return self.cc.import_ct(t.numpy().view(np.uint64).reshape(count, npoly, nl, self.cc.N), scale)
+
+    def _bcast_query(self, q):
+        n = 2 * self.cc.nQ * self.cc.N
+        buf = self._buf("q", n)
+        if self.rank == 0:
+            c, p, l, s = q.shape()
+            assert (c, p, l) == (1, 2, self.cc.nQ), "query must be one fresh ciphertext"
+            self._fill(buf, q)
+        if "q_scale" not in self._bufs:  # agreed once: encryptQuery always encodes at the context's Delta
+            meta = [q.shape()[3] if self.rank == 0 else None]
+            if self.world > 1:
+                self.dist.broadcast_object_list(meta, src=0)
+            self._bufs["q_scale"] = meta[0]
+        elif self.rank == 0 and q.shape()[3] != self._bufs["q_scale"]:
+            raise ValueError("query scale changed between calls")
+        if self.world > 1:
+            self.dist.broadcast(buf, src=0)
+        return q if self.rank == 0 else self._to_ct(buf, 1, 2, self.cc.nQ, self._bufs["q_scale"])
+
+    def _meta(self, key, ct):
+        """(npoly, nl, scale) of a result batch, agreed once per result kind (rank 0 always owns blocks)"""
+        if key not in self._bufs:
+            m = [ct.shape()[1:] if self.rank == 0 else None]
+            if self.world > 1:
+                self.dist.broadcast_object_list(m, src=0)
+            self._bufs[key] = m[0]
+        return self._bufs[key]
+
+    def _gather_blocks(self, key, res):
+        """per-rank [blocks][npoly][nl][N] -> on rank 0 one batch of G ciphertexts in global block order"""
+        npoly, nl, scale = self._meta(key + "_meta", res)
+        per = npoly * nl * self.cc.N
+        send = self._buf(key + "_send", self.max_blocks * per)  # uneven shards: padded to the largest
+        if res is not None:
+            self._fill(send, res)
+        if self.world == 1:
+            return res
+        recv = [self._buf(key + "_recv%d" % r, send.numel()) for r in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(send, recv, dst=0)
+        if self.rank != 0:
+            return None
+        parts = [recv[r][:(hi - lo) * per] for r, (lo, hi) in enumerate(self.ranges) if hi > lo]
+        return self._to_ct(self.torch.cat(parts), self.G, npoly, nl, scale)
+
+    def _local(self, fn_name, q):
+        return getattr(self.local, fn_name)(q) if self.local is not None else None
+
+    def computeSimilarity(self, query_cipher):
+        q = self._bcast_query(query_cipher)
+        return self._gather_blocks("sim", self._local("computeSimilarity", q))
+
+    def indexScenario(self, query_cipher):
+        q = self._bcast_query(query_cipher)
+        return self._gather_blocks("idx", self._local("indexScenario", q))
+
+    def membershipScenario(self, query_cipher):
+        q = self._bcast_query(query_cipher)
+        idx = self._local("indexScenario", q)
+        npoly, nl, scale = self._meta("idx_meta", idx)
+        part = self._buf("mem", npoly * nl * self.cc.N)
+        if idx is not None:
+            self._fill(part, self.cc.add_many(idx))   # EvalAddManyInPlace over this rank's blocks
+        else:
+            part.zero_()
+        if self.world > 1:
+            self.dist.reduce(part, dst=0, op=self.dist.ReduceOp.SUM)   # plain int64 sums: < 16 * 2^60
+        if self.rank != 0:
+            return None
+        tot = self._to_ct(part, 1, npoly, nl, scale)
+        self.cc.ct_mod_reduce(tot)
+        return self.cc.eval_sum(tot)

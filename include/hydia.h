@@ -17,7 +17,8 @@
  *   slots       = IEEE doubles
  * All functions return 0 on success and a negative hydia_status otherwise; hydia_last_error() has the message
  * (the reference prints to cerr and carries on — src/sender/sender_diag.cpp:89-91 — callers that want that behaviour
- * ignore the code).  One host thread per context; contexts are independent (one per GPU).
+ * ignore the code).  One host thread per context at a time; contexts are independent (one per GPU, or several per GPU) and
+ * every entry point selects its context's GPU itself.  A context stays alive until its last hydia_ct handle is freed.
  */
 #ifndef HYDIA_H
 #define HYDIA_H
@@ -80,6 +81,12 @@ int hydia_get_moduli(const hydia_ctx *ctx, uint64_t *moduli, uint64_t *roots);
 int hydia_sync(hydia_ctx *ctx);
 int hydia_memory_stats(hydia_ctx *ctx, uint64_t *pool_live, uint64_t *pool_cached, uint64_t *pool_peak);
 
+/* ---- randomness.  Every seed below is a 32-byte ChaCha20 key; samples are addressed by (seed, nonce), so a (seed, nonce) pair
+ * must NEVER be used for two different plaintexts (the two ciphertexts would differ by exactly the plaintext difference).
+ * The reference draws OpenFHE's PRNG seed from the OS; callers that do not need reproducibility do the same with
+ * hydia_random_seed (getrandom(2)).  Nonces are 40-bit: encryption calls refuse nonce (+ count) >= 2^40. */
+int hydia_random_seed(uint8_t out[32]);
+
 /* ---- keys: cc->KeyGen / EvalMultKeyGen / EvalRotateKeyGen (src/main.cpp:184-206) ---- */
 /* generate sk, pk, relin key and rotation keys {1..dim-1} u {dim, 2dim, .., slots/2} on the GPU from a 32-byte seed */
 int hydia_keygen(hydia_ctx *ctx, const uint8_t seed[32]);
@@ -131,11 +138,21 @@ size_t hydia_db_num_cts(const hydia_ctx *ctx, size_t n_vectors);
  * diagonalises, encodes and encrypts straight into the HBM-resident layout (no serial/db_diagonal files).
  * For a multi-GPU database each rank enrols its own contiguous range of 16384-vector blocks (multi-GPU). */
 int hydia_db_enroll(hydia_ctx *ctx, double *db /* n x vector_dim row-major */, size_t n, const uint8_t seed[32]);
+/* One shard of a database that is cut by 16384-vector row-blocks over several contexts (multi-GPU): `db` holds only
+ * this shard's rows and first_block is the index of its first block in the whole database, so the shard encrypts with exactly
+ * the nonces the unsharded enrolment uses for those blocks (bit-identical ciphertexts). */
+int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block);
 /* or load ciphertexts produced elsewhere: t = block*vector_dim + diagonal, i.e. serial/db_diagonal/index<t>.bin
  * (src/enroller/enroller_diag.cpp:161; read back at src/sender/sender_diag.cpp:87-91) */
 int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors);
 int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data /* [2][n_q][N] */);
 int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data);
+/* Persistence of the enrolled database (the reference keeps one serial/db_diagonal/index<t>.bin per ciphertext,
+ * src/enroller/enroller_diag.cpp:158-166, and re-reads them every query; here the database stays in HBM and a file is only
+ * what a server restart needs).  Own streaming format: a header (parameters, prime chain, packing) + the resident layout
+ * verbatim; hydia_db_load refuses a file written for other parameters / primes / layout. */
+int hydia_db_save(hydia_ctx *ctx, const char *path);
+int hydia_db_load(hydia_ctx *ctx, const char *path);
 /* benchmark filler: n_vectors worth of uniformly random residues (the kernels' cost is data independent) */
 int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed);
 int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_t *bytes);
@@ -153,6 +170,41 @@ int hydia_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **
 int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *in, double delta, size_t sign_depth, hydia_ct **out);
 /* multi-GPU membership tail: sum the batch into one ciphertext, then EvalSum over all slots (:46-47) */
 int hydia_sum_and_evalsum(hydia_ctx *ctx, const hydia_ct *in, hydia_ct **out);
+
+/* The two halves of that tail on their own — what a sharded membership query is composed of (sender_diag.cpp:46-47):
+ * EvalAddManyInPlace over the batch -> ONE ciphertext; EvalSum(ct, batchSize) of one ciphertext. */
+int hydia_add_many(hydia_ctx *ctx, const hydia_ct *in, hydia_ct **out);
+int hydia_eval_sum(hydia_ctx *ctx, const hydia_ct *in, hydia_ct **out);
+/* Cross-shard reduction of the partial sums: acc += src as plain 64-bit integers (src: same shape, compact, in HBM of
+ * src_device; -1 = this context's GPU), and afterwards every value -> its canonical residue.  At most 16 residues below 2^60
+ * fit 64 bits, so an RCCL all-reduce(SUM) on int64 over the handle's memory (hydia_ct_device_ptr) followed by
+ * hydia_ct_mod_reduce is the multi-process form of the same step. */
+int hydia_ct_add_raw(hydia_ctx *ctx, hydia_ct *acc, const void *dev_src, int src_device);
+int hydia_ct_mod_reduce(hydia_ctx *ctx, hydia_ct *ct);
+
+/* ---- sharded sender: one database over R contexts of ONE process (one per GPU of a node; shards may share a GPU) ----
+ * Replaces the serial block loop of DiagonalSender::computeSimilarity (src/sender/sender_diag.cpp:28-30): shard r owns the
+ * contiguous block range hydia_shard_blocks(G, R, r), every shard has the keys (same seed; one resident copy per GPU) and
+ * runs loop A + its own mat-vec + comparator on its own host thread.  Queries enter and results leave through shard 0
+ * (hydia_group_ctx(g, 0): encrypt / import the query there, decrypt there); result batches are in GLOBAL block order, so
+ * hydia_decrypt_index returns database indices.  Results are bit-identical to one context holding the whole database. */
+typedef struct hydia_group hydia_group;
+/* block range [lo, hi) of `rank`: the first total_blocks % world ranks take one extra block (host only, no GPU needed) */
+void hydia_shard_blocks(size_t total_blocks, uint32_t world, uint32_t rank, size_t *lo, size_t *hi);
+int hydia_group_create(const hydia_params *p, const int *devices /* [n_shards] GPU index of each shard */, uint32_t n_shards,
+                       hydia_group **out);
+void hydia_group_destroy(hydia_group *g);
+uint32_t hydia_group_size(const hydia_group *g);
+hydia_ctx *hydia_group_ctx(hydia_group *g, uint32_t shard); /* borrowed: never hydia_ctx_destroy it */
+int hydia_group_keygen(hydia_group *g, const uint8_t seed[32]);
+/* DiagonalEnroller::serializeDB over the group (normalises db IN PLACE); shard r enrols rows [first, first + n) of
+ * hydia_group_shard_range */
+int hydia_group_db_enroll(hydia_group *g, double *db /* n x vector_dim */, size_t n, const uint8_t seed[32]);
+int hydia_group_shard_range(const hydia_group *g, uint32_t shard, size_t *first_vector, size_t *n_vectors);
+/* Sender::computeSimilarity / indexScenario / membershipScenario over all shards; query and *out live in shard 0 */
+int hydia_group_compute_similarity(hydia_group *g, const hydia_ct *query, hydia_ct **out);
+int hydia_group_index_scenario(hydia_group *g, const hydia_ct *query, hydia_ct **out);
+int hydia_group_membership_scenario(hydia_group *g, const hydia_ct *query, hydia_ct **out);
 
 /* ---- HERS, approach 4: the paper's main comparison on the same kernels ---- */
 /* HersEnroller::serializeDB, src/enroller/enroller_hers.cpp:40-93: index-batched (column) packing, vector_dim ciphertexts per

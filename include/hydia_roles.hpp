@@ -5,11 +5,14 @@
 // types are replaced by thin handles onto HBM-resident objects:
 //     CryptoContext<DCRTPoly> + PublicKey + PrivateKey  ->  hydia::CryptoContext (context + keys + resident database)
 //     Ciphertext<DCRTPoly>                               ->  hydia::Ciphertext   (one element of a device batch)
+// Randomness: like the reference (OpenFHE seeds its PRNG from the OS) every role object draws its 32-byte sampler key from the
+// operating system (hydia_random_seed) unless the caller passes one for reproducibility; nonces count up per object.
 // Error behaviour mirrors the reference: a message on cerr and carry on (src/sender/sender_diag.cpp:89-91); the
 // status code of the last failing call is kept in CryptoContext::last_status for callers that want to assert.
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -23,11 +26,21 @@ const double MATCH_THRESHOLD = 0.44;  // include/config.h:9
 const size_t COMP_DEPTH = 10;         // include/config.h:14
 const size_t VECTOR_DIM = 512;        // include/config.h:30
 
+inline void role_seed(uint8_t out[32], const uint8_t *seed32) {
+    if (seed32) {
+        for (int i = 0; i < 32; i++) out[i] = seed32[i];
+    } else if (hydia_random_seed(out) != 0) {
+        std::cerr << "Error: " << hydia_last_error() << std::endl;
+        std::abort();  // never encrypt under a predictable key
+    }
+}
+
 class CryptoContextImpl {
   public:
     hydia_ctx *h = nullptr;
     hydia_info info{};
     int last_status = 0;
+    hydia_group *group = nullptr;  // set when the context is sharded over several GPUs; h is then the group's shard 0
     explicit CryptoContextImpl(const hydia_params &p, int device = 0) {
         last_status = hydia_ctx_create(&p, device, &h);
         if (last_status != 0) {
@@ -37,7 +50,21 @@ class CryptoContextImpl {
         }
         hydia_get_info(h, &info);
     }
-    ~CryptoContextImpl() { hydia_ctx_destroy(h); }
+    // one context per entry of `devices` (DB row-blocks sharded across them); queries and results use shard 0
+    CryptoContextImpl(const hydia_params &p, const std::vector<int> &devices) {
+        last_status = hydia_group_create(&p, devices.data(), (uint32_t)devices.size(), &group);
+        if (last_status != 0) {
+            std::cerr << "Error: " << hydia_last_error() << std::endl;
+            group = nullptr;
+            return;
+        }
+        h = hydia_group_ctx(group, 0);
+        hydia_get_info(h, &info);
+    }
+    ~CryptoContextImpl() {
+        if (group) hydia_group_destroy(group);
+        else hydia_ctx_destroy(h);
+    }
     CryptoContextImpl(const CryptoContextImpl &) = delete;
     CryptoContextImpl &operator=(const CryptoContextImpl &) = delete;
     bool check(int code, const char *what) {
@@ -49,8 +76,13 @@ class CryptoContextImpl {
     }
     size_t GetRingDimension() const { return info.n; }
     size_t GetBatchSize() const { return info.slots; }
-    // cc->KeyGen(); EvalMultKeyGen; EvalSumKeyGen; EvalRotateKeyGen (src/main.cpp:184-206) in one call
-    bool KeyGen(const uint8_t seed[32]) { return check(hydia_keygen(h, seed), "key generation"); }
+    // cc->KeyGen(); EvalMultKeyGen; EvalSumKeyGen; EvalRotateKeyGen (src/main.cpp:184-206) in one call; seed32 == nullptr
+    // draws the key material from the OS
+    bool KeyGen(const uint8_t *seed32 = nullptr) {
+        uint8_t seed[32];
+        role_seed(seed, seed32);
+        return check(group ? hydia_group_keygen(group, seed) : hydia_keygen(h, seed), "key generation");
+    }
 };
 using CryptoContext = std::shared_ptr<CryptoContextImpl>;
 
@@ -63,6 +95,18 @@ inline CryptoContext GenCryptoContext(size_t multDepth = 11, uint32_t scalingMod
     p.vector_dim = vectorDim;
     p.log_n = logN;
     return std::make_shared<CryptoContextImpl>(p, device);
+}
+// the same context sharded over several GPUs (or several shards on one): DiagonalEnroller / DiagonalSender then work on
+// the whole group, each GPU owning a contiguous range of 16384-vector blocks
+inline CryptoContext GenShardedCryptoContext(const std::vector<int> &devices, size_t multDepth = 11, uint32_t scalingModSize = 45,
+                                             uint32_t vectorDim = 512, uint32_t logN = 15) {
+    hydia_params p;
+    hydia_default_params(&p);
+    p.mult_depth = (uint32_t)multDepth;
+    p.scale_bits = scalingModSize;
+    p.vector_dim = vectorDim;
+    p.log_n = logN;
+    return std::make_shared<CryptoContextImpl>(p, devices);
 }
 
 // one ciphertext = (shared device batch, index inside it)
@@ -115,36 +159,35 @@ class Sender {
     CryptoContext cc;
     size_t numVectors;
 };
-// ---- include/sender_diag.h:5-28 (HersSender, approach 4, is further down)
+// ---- include/sender_diag.h:5-28 (HersSender, approach 4, is further down).  On a sharded context (GenShardedCryptoContext)
+// the same three methods run over every GPU of the group: per-shard mat-vec, results back in global block order, membership
+// as per-shard EvalAddMany -> integer sum -> mod q -> EvalSum (hydia.h, "sharded sender").
 class DiagonalSender : public Sender {
   public:
     DiagonalSender(CryptoContext ccParam, size_t vectorParam) : Sender(std::move(ccParam), vectorParam) {}
     std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) override {
-        hydia_ct *out = nullptr;
-        if (!query_ok(queryCipher) || !cc->check(hydia_compute_similarity(cc->h, queryCipher[0].batch->h, &out), "computeSimilarity"))
-            return {};
-        return split_batch(cc, out);
+        hydia_ct *out = run(queryCipher, hydia_compute_similarity, hydia_group_compute_similarity, "computeSimilarity");
+        return out ? split_batch(cc, out) : std::vector<Ciphertext>{};
     }
     Ciphertext membershipScenario(std::vector<Ciphertext> &queryCipher) override {
-        hydia_ct *out = nullptr;
-        if (!query_ok(queryCipher) || !cc->check(hydia_membership_scenario(cc->h, queryCipher[0].batch->h, &out), "membershipScenario"))
-            return Ciphertext{};
-        return split_batch(cc, out)[0];
+        hydia_ct *out = run(queryCipher, hydia_membership_scenario, hydia_group_membership_scenario, "membershipScenario");
+        return out ? split_batch(cc, out)[0] : Ciphertext{};
     }
     std::vector<Ciphertext> indexScenario(std::vector<Ciphertext> &queryCipher) override {
-        hydia_ct *out = nullptr;
-        if (!query_ok(queryCipher) || !cc->check(hydia_index_scenario(cc->h, queryCipher[0].batch->h, &out), "indexScenario"))
-            return {};
-        return split_batch(cc, out);
+        hydia_ct *out = run(queryCipher, hydia_index_scenario, hydia_group_index_scenario, "indexScenario");
+        return out ? split_batch(cc, out) : std::vector<Ciphertext>{};
     }
 
   private:
-    bool query_ok(std::vector<Ciphertext> &q) {
+    hydia_ct *run(std::vector<Ciphertext> &q, int (*one)(hydia_ctx *, const hydia_ct *, hydia_ct **),
+                  int (*sharded)(hydia_group *, const hydia_ct *, hydia_ct **), const char *what) {
         if (q.empty() || !q[0]) {
             std::cerr << "Error: empty query ciphertext" << std::endl;
-            return false;
+            return nullptr;
         }
-        return true;
+        hydia_ct *out = nullptr;
+        const int code = cc->group ? sharded(cc->group, q[0].batch->h, &out) : one(cc->h, q[0].batch->h, &out);
+        return cc->check(code, what) ? out : nullptr;
     }
 };
 
@@ -186,7 +229,7 @@ class DiagonalReceiver : public HersReceiver {
   public:
     DiagonalReceiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
         : HersReceiver(std::move(ccParam), vectorParam) {
-        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0xA5 ^ i);
+        role_seed(seed, seed32);
     }
     // src/receiver/receiver_diag.cpp:13-26
     std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
@@ -206,7 +249,7 @@ class DiagonalEnroller {
   public:
     DiagonalEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
         : cc(std::move(ccParam)), numVectors(vectorParam) {
-        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0x5A ^ i);
+        role_seed(seed, seed32);
     }
     // src/enroller/enroller_diag.cpp:12-53 — normalises `database` in place; ciphertexts go to HBM, not to
     // serial/db_diagonal/index<t>.bin
@@ -215,7 +258,10 @@ class DiagonalEnroller {
         std::vector<double> flat(numVectors * dim, 0.0);
         for (size_t i = 0; i < numVectors && i < database.size(); i++)
             for (size_t j = 0; j < dim && j < database[i].size(); j++) flat[i * dim + j] = database[i][j];
-        if (!cc->check(hydia_db_enroll(cc->h, flat.data(), numVectors, seed), "serializeDB")) return;
+        if (!cc->check(cc->group ? hydia_group_db_enroll(cc->group, flat.data(), numVectors, seed)
+                                 : hydia_db_enroll(cc->h, flat.data(), numVectors, seed),
+                       "serializeDB"))
+            return;
         for (size_t i = 0; i < numVectors && i < database.size(); i++)
             for (size_t j = 0; j < dim && j < database[i].size(); j++) database[i][j] = flat[i * dim + j];
     }
@@ -257,7 +303,7 @@ class HersQueryReceiver : public HersReceiver {  // HersReceiver with its own en
   public:
     HersQueryReceiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
         : HersReceiver(std::move(ccParam), vectorParam) {
-        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0xC3 ^ i);
+        role_seed(seed, seed32);
     }
     std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
         hydia_ct *out = nullptr;
@@ -275,7 +321,7 @@ class HersEnroller {
   public:
     HersEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
         : cc(std::move(ccParam)), numVectors(vectorParam) {
-        for (int i = 0; i < 32; i++) seed[i] = seed32 ? seed32[i] : (uint8_t)(0x3C ^ i);
+        role_seed(seed, seed32);
     }
     void serializeDB(std::vector<std::vector<double>> &database) {  // enroller_hers.cpp:40-93
         const size_t dim = cc->info.vector_dim;

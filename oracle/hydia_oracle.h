@@ -149,6 +149,9 @@ hy_ct **hyo_compute_similarity(const hy_params *p, const hy_keys *k, const hy_ct
 hy_ct **hyo_index_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n,
                            size_t *n_out);
 hy_ct *hyo_membership_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n);
+/* the reference's per-ciphertext file hand-off (enroller_diag.cpp:158-166, sender_diag.cpp:85-94); own raw format */
+int hyo_db_write_files(const hy_params *p, hy_ct **db, size_t count, const char *dir);
+hy_ct **hyo_index_scenario_files(const hy_params *p, const hy_keys *k, const hy_ct *q, const char *dir, size_t n, size_t *n_out);
 int hyo_decrypt_membership(const hy_params *p, const hy_keys *k, const hy_ct *c);
 size_t hyo_decrypt_index(const hy_params *p, const hy_keys *k, hy_ct **cts, size_t n_cts, size_t *out,
                          size_t cap);

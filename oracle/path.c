@@ -436,6 +436,95 @@ hy_ct **hyo_index_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q,
     }
     return score;
 }
+/* ---- the reference's on-disk hand-off between enroller and sender.  DiagonalEnroller::serializeDBThread writes one file per
+ * ciphertext, "serial/db_diagonal/index<t>.bin" (enroller_diag.cpp:158-166), and computeSimilarityThread reads its file back
+ * INSIDE the timed parallel loop of every query (sender_diag.cpp:85-94).  OpenFHE's cereal BINARY layout is undocumented in the
+ * reference and not reproduced: a file here is a small header + the raw residues.  Used by bench.py's cpu_baseline to time the
+ * variant that pays the reference's per-query I/O. */
+int hyo_db_write_files(const hy_params *p, hy_ct **db, size_t count, const char *dir) {
+    int ok = 1;
+#pragma omp parallel for schedule(dynamic) reduction(&& : ok)
+    for (size_t t = 0; t < count; t++) {
+        char path[4096];
+        snprintf(path, sizeof path, "%s/index%zu.bin", dir, t);
+        FILE *f = fopen(path, "wb");
+        if (!f) {
+            ok = 0;
+            continue;
+        }
+        int hdr[2] = {db[t]->npoly, db[t]->nl};
+        size_t n = (size_t)db[t]->npoly * db[t]->nl * p->N;
+        ok = ok && fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(&db[t]->scale, sizeof(double), 1, f) == 1 &&
+             fwrite(db[t]->d, sizeof(u64), n, f) == n;
+        fclose(f);
+    }
+    return ok ? 0 : -1;
+}
+static hy_ct *read_ct_file(const hy_params *p, const char *dir, size_t t) {
+    char path[4096];
+    snprintf(path, sizeof path, "%s/index%zu.bin", dir, t);
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        fprintf(stderr, "Error: Cannot read serialization from %s\n", path); /* sender_diag.cpp:89-91 */
+        return NULL;
+    }
+    int hdr[2];
+    double scale;
+    hy_ct *c = NULL;
+    if (fread(hdr, sizeof hdr, 1, f) == 1 && fread(&scale, sizeof scale, 1, f) == 1) {
+        c = hyo_ct_alloc(p, hdr[0], hdr[1], scale);
+        size_t n = (size_t)hdr[0] * hdr[1] * p->N;
+        if (fread(c->d, sizeof(u64), n, f) != n) {
+            hyo_ct_free(c);
+            c = NULL;
+        }
+    }
+    fclose(f);
+    return c;
+}
+/* indexScenario whose loop B deserialises index<m*dim+i>.bin per product (sender_diag.cpp:66-94), then compares (:57-60) */
+hy_ct **hyo_index_scenario_files(const hy_params *p, const hy_keys *k, const hy_ct *q, const char *dir, size_t n, size_t *n_out) {
+    size_t G = (n + p->slots - 1) / p->slots;
+    int dim = p->dim;
+    hy_ct **rot = hyo_rotate_query(p, k, q);
+    hy_ct **score = (hy_ct **)calloc(G, sizeof(hy_ct *));
+    for (size_t m = 0; m < G; m++) {
+        hy_ct **prod = (hy_ct **)calloc(dim, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+        for (int i = 0; i < dim; i++) {
+            hy_ct *dbc = read_ct_file(p, dir, m * dim + i);
+            if (dbc) {
+                prod[i] = hyo_mult_norelin(p, rot[i], dbc);
+                hyo_ct_free(dbc);
+            }
+        }
+        hy_ct *acc = NULL;
+        for (int i = 0; i < dim; i++) {
+            if (!prod[i]) continue;
+            if (!acc) acc = prod[i];
+            else {
+                hyo_add_inplace(p, acc, prod[i]);
+                hyo_ct_free(prod[i]);
+            }
+        }
+        free(prod);
+        if (acc) {
+            hyo_relin_inplace(p, k, acc);
+            hyo_rescale_inplace(p, acc);
+        }
+        score[m] = acc;
+    }
+    hyo_ct_array_free(rot, dim);
+#pragma omp parallel for
+    for (size_t i = 0; i < G; i++) {
+        if (!score[i]) continue;
+        hy_ct *c = hyo_chebyshev_compare(p, k, score[i], MATCH_THRESHOLD, COMP_DEPTH);
+        hyo_ct_free(score[i]);
+        score[i] = c;
+    }
+    *n_out = G;
+    return score;
+}
 /* DiagonalSender::membershipScenario, sender_diag.cpp:35-50: EvalAddManyInPlace then EvalSum over batchSize */
 hy_ct *hyo_membership_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n) {
     size_t G;

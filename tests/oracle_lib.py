@@ -91,6 +91,8 @@ def lib():
         "hyo_compute_similarity": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
         "hyo_index_scenario": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
         "hyo_membership_scenario": (vp, [vp, vp, vp, vp, C.c_size_t]),
+        "hyo_db_write_files": (C.c_int, [vp, vp, C.c_size_t, C.c_char_p]),
+        "hyo_index_scenario_files": (vp, [vp, vp, vp, C.c_char_p, C.c_size_t, vp]),
         "hyo_decrypt_membership": (C.c_int, [vp, vp, vp]),
         "hyo_decrypt_index": (C.c_size_t, [vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
         "hyo_hers_layout_row": (None, [vp, vp, C.c_size_t, C.c_size_t, vp]),
@@ -406,6 +408,16 @@ class Oracle:
 
     def membership_scenario(self, q, db, n):
         return Ct(self.P, self.L.hyo_membership_scenario(self.P.h, self.K.h, q.h, db.h, n))
+
+    def write_db_files(self, db, directory):
+        """one index<t>.bin per ciphertext (enroller_diag.cpp:158-166)"""
+        assert self.L.hyo_db_write_files(self.P.h, db.h, len(db), str(directory).encode()) == 0
+
+    def index_scenario_files(self, q, directory, n):
+        """indexScenario that re-reads every database ciphertext from disk inside loop B (sender_diag.cpp:85-94)"""
+        n_out = C.c_size_t(0)
+        h = self.L.hyo_index_scenario_files(self.P.h, self.K.h, q.h, str(directory).encode(), n, C.byref(n_out))
+        return CtArray(self.P, h, n_out.value)
 
     # ---- HERS (approach 4)
     def hers_enroll(self, db, seed):

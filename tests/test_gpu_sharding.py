@@ -1,0 +1,287 @@
+"""GPU tests of the sharded DiagonalSender (run with -m gpu; one MI355X is enough): R shards — contexts that share the GPU —
+must reproduce, bit for bit, the ciphertexts ONE context holding the whole database computes
+(/root/reference/src/sender/sender_diag.cpp:28-30 blocks are independent; :46-49 membership tail), through both drivers:
+the in-process group (libhydia hydia_group_*, what ./ImageMatching uses) and the one-process-per-GPU class bench.py uses
+(here two ranks over gloo that both compute on GPU 0).  Also the re-key and handle-lifetime regressions of round 1's review."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def im():
+    import image_matching_amd as im
+    return im
+
+
+def make_db(n, dim, planted, seed):
+    rng = np.random.default_rng(seed)
+    db = rng.integers(-99, 100, size=(n, dim)).astype(np.float64)
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=dim)
+    return db
+
+
+def single_context_results(im, prm, n, db, planted, query, kseed=31, dseed=8, qseed=2):
+    cc = im.Context(prm, 0)
+    cc.keygen(kseed)
+    a = db.copy()
+    im.DiagonalEnroller(cc, n).serializeDB(a, seed=dseed)
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    q = receiver.encryptQuery(query, seed=qseed, nonce=9)
+    idx = sender.indexScenario(q)
+    assert receiver.decryptIndex(idx) == sorted(planted)
+    out = dict(q=q.export(), qscale=q.shape()[3], sim=sender.computeSimilarity(q).export(), idx=idx.export(),
+               mem=sender.membershipScenario(q).export(), normalised=a,
+               db_cts={t: cc.db_export_ct(t) for t in (0, cc.dim + 1, cc.db_stats()[1] - 1)})
+    del q, idx
+    cc.close()
+    return out
+
+
+def check_group(im, prm, devices, n, db, planted, query, want):
+    grp = im.ShardGroup(devices, prm)
+    grp.keygen(31)
+    b = db.copy()
+    im.ShardedDiagonalEnroller(grp, n).serializeDB(b, seed=8)
+    assert np.array_equal(b, want["normalised"])  # normalised in place, like one enroller
+    cc0 = grp.ctx0
+    S, dim = cc0.slots, cc0.dim
+    G = -(-n // S)
+    # the shards together hold exactly the single context's ciphertexts (same nonces): spot-check through the shard that owns them
+    for t, data in want["db_cts"].items():
+        g = t // dim
+        r = next(r for r in range(len(devices)) if im.shard_blocks(G, len(devices), r)[0] <= g < im.shard_blocks(G, len(devices), r)[1])
+        lo = im.shard_blocks(G, len(devices), r)[0]
+        assert np.array_equal(grp.shard_ctx(r).db_export_ct(t - lo * dim), data), (t, r)
+    first, cnt = grp.shard_range(len(devices) - 1)
+    assert first + cnt == n or cnt == 0
+    sender, receiver = im.ShardedDiagonalSender(grp, n), im.DiagonalReceiver(cc0, n)
+    q = receiver.encryptQuery(query, seed=2, nonce=9)
+    assert np.array_equal(q.export(), want["q"])
+    assert np.array_equal(sender.computeSimilarity(q).export(), want["sim"])
+    idx = sender.indexScenario(q)
+    assert np.array_equal(idx.export(), want["idx"])          # global block order
+    assert receiver.decryptIndex(idx) == sorted(planted)       # global indices
+    mem = sender.membershipScenario(q)
+    assert np.array_equal(mem.export(), want["mem"])           # add-many -> integer sum -> mod q -> EvalSum
+    assert receiver.decryptMembership(mem) == (len(planted) > 0)
+    del q, idx, mem
+    grp.close()
+
+
+@pytest.mark.parametrize("n,planted", [(5000, [0, 1024, 4999]), (700, [13]), (3100, [])])
+def test_shard_group_bit_identical_small_ring(im, n, planted):
+    """N = 2^11 (1024-vector blocks): 5, 1 and 4 blocks over 2, 3 and 5 shards — uneven and empty shards included."""
+    prm = im.default_params(log_n=11, vector_dim=64)
+    db = make_db(n, 64, planted, n)
+    query = np.ones(64)
+    want = single_context_results(im, prm, n, db, planted, query)
+    for R in (2, 3, 5):
+        check_group(im, prm, [0] * R, n, db, planted, query, want)
+
+
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_shard_group_2p17_full_ring(im, R, full_ring_2p17):
+    """BASELINE config 4's database (2^17 vectors = 8 blocks, N = 2^15) over R shards on one GPU: index ciphertexts identical to
+    the single-context run, membership ciphertext identical after the mod."""
+    n, db, planted, query, want = full_ring_2p17
+    check_group(im, im.default_params(), [0] * R, n, db, planted, query, want)
+
+
+@pytest.fixture(scope="module")
+def full_ring_2p17(im):
+    n = 1 << 17
+    planted = [5, 16384 * 3 + 7, n - 1]
+    rng = np.random.default_rng(17)
+    db = rng.integers(-99, 100, size=(n, 512), dtype=np.int8).astype(np.float64)
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    query = np.ones(512)
+    return n, db, planted, query, single_context_results(im, im.default_params(), n, db, planted, query)
+
+
+RANK_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import torch.distributed as dist
+import image_matching_amd as im
+from test_gpu_sharding import make_db
+rank, world, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[2])
+dist.init_process_group("gloo")
+prm = im.default_params(log_n=11, vector_dim=64)
+cc = im.Context(prm, 0)
+cc.keygen(31)
+planted = [0, 1024, n - 1]
+db = make_db(n, 64, planted, n)
+enr = im.DistDiagonalEnroller(cc, n, rank, world)
+enr.serializeDB(np.ascontiguousarray(db[enr.first:enr.last]), seed=8)
+sender = im.DistDiagonalSender(cc, n, dist, rank, world, staging="host")
+receiver = im.DiagonalReceiver(cc, n)
+q = receiver.encryptQuery(np.ones(64), seed=2, nonce=9) if rank == 0 else None
+sim, idx, mem = sender.computeSimilarity(q), sender.indexScenario(q), sender.membershipScenario(q)
+if rank == 0:
+    assert receiver.decryptIndex(idx) == planted and receiver.decryptMembership(mem) is True
+    np.savez(sys.argv[3], sim=sim.export(), idx=idx.export(), mem=mem.export())
+dist.barrier()
+dist.destroy_process_group()
+cc.close()
+'''
+
+
+def test_dist_sender_two_ranks_on_one_gpu(im, tmp_path):
+    """bench.py's multi-rank class with two real ranks (gloo, host staging; both contexts on GPU 0): rank 0's gathered index /
+    similarity batches and reduced membership ciphertext equal the single-context ones bit for bit."""
+    n = 5000
+    prm = im.default_params(log_n=11, vector_dim=64)
+    planted = [0, 1024, n - 1]
+    db = make_db(n, 64, planted, n)
+    want = single_context_results(im, prm, n, db, planted, np.ones(64))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    out = tmp_path / "rank0.npz"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(out)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = np.load(out)
+    for k in ("sim", "idx", "mem"):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_rekey_refreshes_loop_a_keys(im):
+    """keygen(a), query, keygen(b) on the SAME context, query: must equal a fresh context keyed with b (loop A streams a packed
+    shadow of the rotation keys that has to follow every re-key — round-1 advisor finding)."""
+    prm = im.default_params(log_n=11, vector_dim=64)
+    n = 1500
+    db = make_db(n, 64, [3], 1)
+
+    def run(cc):
+        im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=8)
+        q = im.DiagonalReceiver(cc, n).encryptQuery(np.ones(64), seed=2, nonce=9)
+        s = im.DiagonalSender(cc, n)
+        return s.rotateQuery(q).export(), s.indexScenario(q).export()
+    cc = im.Context(prm, 0)
+    cc.keygen(100)
+    first = run(cc)
+    cc.keygen(200)
+    again = run(cc)
+    fresh = im.Context(prm, 0)
+    fresh.keygen(200)
+    want = run(fresh)
+    assert not np.array_equal(first[0], want[0])
+    assert np.array_equal(again[0], want[0]) and np.array_equal(again[1], want[1])
+    # the same through an imported key: overwrite rotation key 1 with another context's and expect that context's rotation
+    other = im.Context(prm, 0)
+    other.keygen(300)
+    for r in range(1, 64):
+        cc.import_eval_key(r, other.export_eval_key(r))
+    cc.import_eval_key(0, other.export_eval_key(0))
+    cc.import_public_key(other.export_public_key())
+    assert np.array_equal(run(cc)[0], run(other)[0])
+    for c in (cc, fresh, other):
+        c.close()
+
+
+def test_handles_outlive_context_close(im):
+    """hydia_ct_free after hydia_ctx_destroy (round-1 advisor finding): the context is kept alive by its handles."""
+    cc = im.Context(im.default_params(log_n=11, vector_dim=64), 0)
+    cc.keygen(1)
+    ct = cc.encrypt(np.zeros((2, cc.slots)), seed=1)
+    L = cc.L
+    cc.close()
+    assert ct.shape()[:3] == (2, 2, 12)
+    del ct  # frees the handle, which completes the deferred destruction
+    with pytest.raises(im.HydiaError):  # shape validation of device imports
+        c2 = im.Context(im.default_params(log_n=11, vector_dim=64), 0)
+        try:
+            c2.ct_from_device(1, 1, 7, 2, 1.0)
+        finally:
+            c2.close()
+    with pytest.raises(im.HydiaError) as e:  # nonces are 40-bit
+        c3 = im.Context(im.default_params(log_n=11, vector_dim=64), 0)
+        try:
+            c3.keygen(1)
+            c3.encrypt(np.zeros((1, c3.slots)), seed=1, nonce0=1 << 40)
+        finally:
+            c3.close()
+    assert e.value.code == -1
+    # two encryptions with default seeds differ (OS entropy), two with the same (seed, nonce) agree
+    c4 = im.Context(im.default_params(log_n=11, vector_dim=64), 0)
+    c4.keygen(None)
+    z = np.zeros((1, c4.slots))
+    assert not np.array_equal(c4.encrypt(z).export(), c4.encrypt(z).export())
+    assert np.array_equal(c4.encrypt(z, seed=5, nonce0=3).export(), c4.encrypt(z, seed=5, nonce0=3).export())
+    c4.close()
+
+
+def test_cli_sharded_matches_reference_answers(tmp_path):
+    """./ImageMatching <2_10.dat> 5 with HYDIA_DEVICES=0,0 (two shards on the one GPU): the sharded roles behind the reference's
+    driver flow give `true`, `[ 0 ]`."""
+    exe = os.path.join(ROOT, "image_matching_amd", "ImageMatching")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    g = np.load(os.path.join(GOLDEN, "dataset_2_11.npz"))
+    dat = tmp_path / "2_11.dat"
+    with open(dat, "w") as f:
+        f.write("%d\n" % int(g["n"]))
+        f.write(" ".join(str(int(v)) for v in g["query"]) + " \n")
+        for row in g["db"]:
+            f.write(" ".join(str(int(v)) for v in row) + " \n")
+    (tmp_path / "latency.csv").write_text("")
+    out = subprocess.run([exe, str(dat), "5"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, HYDIA_DEVICES="0,0", HYDIA_SEED="7"))
+    assert out.returncode == 0, out.stderr
+    assert "Membership scenario: true" in out.stdout and "Index scenario: [ 0 ]" in out.stdout
+    row = (tmp_path / "latency.csv").read_text().strip().split(",")
+    assert row[0] == "Diagonal" and row[1] == "2048" and row[10] == "true" and row[11] == "[ 0 ]"
+
+
+def test_db_save_load_round_trip(im, tmp_path):
+    """hydia_db_save / hydia_db_load: enrol, save, NEW context, load, and indexScenario is bit-identical (no re-enrolment);
+    a file written for another prime chain or ring is refused."""
+    prm = im.default_params(log_n=11, vector_dim=64)
+    n, planted = 3000, [1, 2999]
+    db = make_db(n, 64, planted, 5)
+    cc = im.Context(prm, 0)
+    cc.keygen(31)
+    im.DiagonalEnroller(cc, n).serializeDB(db, seed=8)
+    q = im.DiagonalReceiver(cc, n).encryptQuery(np.ones(64), seed=2, nonce=9)
+    want = im.DiagonalSender(cc, n).indexScenario(q).export()
+    path = tmp_path / "db.hydia"
+    cc.db_save(path)
+    stats = cc.db_stats()
+    assert os.path.getsize(path) > stats[2]
+    c2 = im.Context(prm, 0)
+    c2.keygen(31)
+    with pytest.raises(im.HydiaError):
+        c2.db_save(tmp_path / "none.hydia")  # nothing resident
+    c2.db_load(path)
+    assert c2.db_stats() == stats
+    q2 = c2.import_ct(q.export(), q.shape()[3])
+    assert np.array_equal(im.DiagonalSender(c2, n).indexScenario(q2).export(), want)
+    assert im.DiagonalReceiver(c2, n).decryptIndex(im.DiagonalSender(c2, n).indexScenario(q2)) == planted
+    c3 = im.Context(im.default_params(log_n=12, vector_dim=64), 0)
+    with pytest.raises(im.HydiaError):
+        c3.db_load(path)
+    with pytest.raises(im.HydiaError):
+        c2.db_load(tmp_path / "missing.hydia")
+    del q, q2
+    for c in (cc, c2, c3):
+        c.close()

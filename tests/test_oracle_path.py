@@ -165,3 +165,22 @@ def test_custom_prime_chain_context():
     bad[3] += 2
     with pytest.raises(ValueError):
         O.Params(log_n=11, depth=11, dim=64, moduli=bad, n_p=4)
+
+
+def test_file_handoff_variant_equals_in_memory_path(small_params, small_keys, tmp_path):
+    """The reference's sender re-reads serial/db_diagonal/index<t>.bin inside loop B (sender_diag.cpp:85-94); the oracle's
+    file-backed indexScenario (bench.py's disk-reread CPU baseline) gives the same ciphertexts as the in-memory one."""
+    P, K = small_params, small_keys
+    Or = O.Oracle(P, K)
+    rng = np.random.default_rng(3)
+    n = 2100
+    db = synth_db(rng, n, P.dim, [7, 2000])
+    dbc = Or.enroll(db, 9)
+    Or.write_db_files(dbc, tmp_path)
+    assert len(list(tmp_path.iterdir())) == len(dbc)
+    q = Or.encrypt_query(np.ones(P.dim), 5, 1)
+    a, b = Or.index_scenario(q, dbc, n), Or.index_scenario_files(q, tmp_path, n)
+    assert len(a) == len(b) == 3
+    for g in range(3):
+        assert np.array_equal(a[g].data(), b[g].data())
+    assert Or.decrypt_index(b) == [7, 2000]

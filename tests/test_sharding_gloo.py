@@ -1,15 +1,77 @@
-"""Multi-GPU path on CPU: world_size-2 gloo runs of the block sharding + result gather + membership all-reduce that
-bench.py uses over RCCL."""
+"""The multi-process sharded sender (image_matching_amd.sharding.DistDiagonalSender — the class bench.py --gpus N runs over
+RCCL) on CPU: world-size-2 and -3 gloo groups drive the REAL host logic (block ranges from libhydia's hydia_shard_blocks,
+query broadcast, padded gather of uneven shards into global block order, membership = local add-many -> integer reduce ->
+mod q -> EvalSum) over a stand-in engine that does the per-rank ciphertext arithmetic with numpy on synthetic residues.
+What the stand-in replaces is exactly the part that needs a GPU; tests/test_gpu_sharding.py runs the same class on real
+contexts and requires bit-equality with the unsharded sender."""
 import os
 import socket
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from image_matching_amd import sharding
+
+Q = [1152921504606584833, 35184372744193]  # one 60-bit and one 45-bit prime: limb 0 and limb 1 of the fake results
+N, SLOTS, NQ = 64, 32, 3
+
+
+class FakeCt:
+    def __init__(self, data, scale):
+        self.data, self.scale = np.ascontiguousarray(data, dtype=np.uint64), scale
+
+    def shape(self):
+        c, p, l, _ = self.data.shape
+        return c, p, l, self.scale
+
+    def export(self):
+        return self.data.copy()
+
+
+class FakeContext:
+    """numpy stand-in for the rank-local engine: same method names as image_matching_amd.Context"""
+    N, slots, nQ, dim = N, SLOTS, NQ, 4
+
+    def import_ct(self, data, scale):
+        return FakeCt(data, scale)
+
+    def add_many(self, ct):
+        tot = np.zeros_like(ct.data[0], dtype=object)
+        for x in ct.data:
+            tot = tot + x.astype(object)
+        for l in range(tot.shape[1]):
+            tot[:, l] %= Q[l]
+        return FakeCt(tot.astype(np.uint64)[None], ct.scale)
+
+    def ct_mod_reduce(self, ct):
+        for l in range(ct.data.shape[2]):
+            ct.data[:, :, l] %= np.uint64(Q[l])
+
+    def eval_sum(self, ct):  # stand-in for the rotate-and-add tree: any deterministic function of the reduced sum
+        return FakeCt((ct.data * np.uint64(3)) % np.uint64(Q[0] if ct.data.shape[2] == 1 else 1 << 62), ct.scale)
+
+
+def block_result(g, kind):
+    """what `kind` gives for GLOBAL block g: [2][2 limbs][N] residues (depends on g only, so any sharding must agree)"""
+    rng = np.random.default_rng(1000 * kind + g)
+    return np.stack([rng.integers(0, Q[l], size=(2, N), dtype=np.uint64) for l in range(2)], axis=1)
+
+
+class FakeSender:
+    def __init__(self, lo, hi, query_check):
+        self.lo, self.hi, self.query_check = lo, hi, query_check
+
+    def _run(self, q, kind):
+        assert np.array_equal(q.export(), self.query_check), "every rank must receive rank 0's query"
+        return FakeCt(np.stack([block_result(g, kind) for g in range(self.lo, self.hi)]), 2.0 ** 45)
+
+    def computeSimilarity(self, q):
+        return self._run(q, 1)
+
+    def indexScenario(self, q):
+        return self._run(q, 2)
 
 
 def test_shard_blocks_partition():
@@ -19,10 +81,9 @@ def test_shard_blocks_partition():
             assert ranges[0][0] == 0 and ranges[-1][1] == G
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
             sizes = [hi - lo for lo, hi in ranges]
-            assert max(sizes) - min(sizes) <= 1
-    lo, hi = sharding.shard_vectors(100000, 16384, 2, 1)
-    assert (lo, hi) == (4 * 16384, 100000)
-    assert sharding.global_indices([0, 5], 32768) == [32768, 32773]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert sharding.shard_vectors(100000, 16384, 2, 1) == (4 * 16384, 100000)
+    assert sharding.shard_vectors(1024, 16384, 4, 2) == (1024, 1024)  # more ranks than blocks: empty shard
 
 
 def _free_port():
@@ -33,44 +94,46 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, G, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # each rank "computed" result ciphertexts for its own blocks: [blocks][2][1][N] of residues
-    N, moduli = 64, [1152921504606584833]
-    lo, hi = sharding.shard_blocks(6, world, rank)
-    rng = np.random.default_rng(100 + rank)
-    local = torch.from_numpy(rng.integers(0, moduli[0], size=(hi - lo, 2, 1, N), dtype=np.int64))
-    got = sharding.gather_results(local.reshape(-1), dist, rank, world)
+    cc = FakeContext()
+    query = np.random.default_rng(5).integers(0, Q[0], size=(1, 2, NQ, N), dtype=np.uint64)
+    n_total = G * SLOTS - 5  # ragged last block
+    lo, hi = sharding.shard_blocks(G, world, rank)
+    sender = sharding.DistDiagonalSender(cc, n_total, dist, rank, world, staging="host",
+                                         make_sender=lambda c, n: FakeSender(lo, hi, query))
+    assert (sender.lo, sender.hi) == (lo, hi) and (sender.local is None) == (hi == lo)
+    q = FakeCt(query, 2.0 ** 45) if rank == 0 else None
+    for _ in range(2):  # second call reuses the cached buffers / metadata
+        idx = sender.indexScenario(q)
+        sim = sender.computeSimilarity(q)
+        mem = sender.membershipScenario(q)
     if rank == 0:
-        for r in range(world):
-            rr = np.random.default_rng(100 + r)
-            rlo, rhi = sharding.shard_blocks(6, world, r)
-            want = rr.integers(0, moduli[0], size=(rhi - rlo, 2, 1, N), dtype=np.int64).reshape(-1)
-            assert np.array_equal(got[r].numpy(), want)
-    # membership: sum of per-rank partial ciphertexts modulo q
-    part = torch.from_numpy(rng.integers(0, moduli[0], size=(2, N), dtype=np.int64))
-    mine = part.clone()
-    red = sharding.allreduce_membership_residues(part, moduli * 2, dist)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
-    tot = np.zeros((2, N), dtype=object)
-    for p_ in parts:
-        tot = tot + p_.numpy().astype(object)
-    assert np.array_equal(red.numpy().astype(object), tot % moduli[0])
-    q.put((rank, True))
+        want_idx = np.stack([block_result(g, 2) for g in range(G)])
+        want_sim = np.stack([block_result(g, 1) for g in range(G)])
+        assert idx.shape() == (G, 2, 2, 2.0 ** 45) and np.array_equal(idx.export(), want_idx)  # global block order
+        assert np.array_equal(sim.export(), want_sim)
+        single = FakeContext()
+        want_mem = single.eval_sum(single.add_many(FakeCt(want_idx, 2.0 ** 45)))  # what ONE context computes
+        assert np.array_equal(mem.export(), want_mem.export())
+    else:
+        assert idx is None and sim is None and mem is None
+    out.put((rank, True))
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_and_allreduce_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,G", [(2, 5), (2, 1), (3, 8)])
+def test_dist_sender_host_logic(world, G):
+    port = _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, G, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == [0, 1]
+    assert sorted(out.get(timeout=5)[0] for _ in range(world)) == list(range(world))
