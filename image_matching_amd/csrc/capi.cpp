@@ -301,8 +301,8 @@ int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, ui
     REQUIRE(ctx && dev_ptr && out, "null argument");
     REQUIRE(count >= 1 && (n_polys == 2 || n_polys == 3) && n_limbs >= 1 && (int)n_limbs <= ctx->cx.nQ, "bad ciphertext shape");
     Ct c(&ctx->cx, (int)count, (int)n_polys, (int)n_limbs, scale);
-    ctx->cx.sync();
-    HIP_CHECK(hipMemcpy(c.d, dev_ptr, c.bytes(), hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpyAsync(c.d, dev_ptr, c.bytes(), hipMemcpyDeviceToDevice, ctx->cx.stream));
+    ctx->cx.sync();  // the caller's buffer is free again, and later work on the context's stream is ordered behind the copy
     *out = wrap(ctx, std::move(c));
     return HYDIA_OK;
     API_END
@@ -534,9 +534,11 @@ int hydia_ct_add_raw(hydia_ctx *ctx, hydia_ct *acc, const void *dev_src, int src
     REQUIRE(ctx && acc && dev_src, "null argument");
     Context &cx = ctx->cx;
     u64 *tmp = cx.pool.get(acc->c.bytes());
-    cx.sync();
-    if (src_device < 0 || src_device == cx.device) HIP_CHECK(hipMemcpy(tmp, dev_src, acc->c.bytes(), hipMemcpyDeviceToDevice));
-    else HIP_CHECK(hipMemcpyPeer(tmp, cx.device, dev_src, src_device, acc->c.bytes()));
+    // on the context's own stream: a plain device-to-device hipMemcpy would run on the null stream, unordered with it
+    if (src_device < 0 || src_device == cx.device)
+        HIP_CHECK(hipMemcpyAsync(tmp, dev_src, acc->c.bytes(), hipMemcpyDeviceToDevice, cx.stream));
+    else
+        HIP_CHECK(hipMemcpyPeerAsync(tmp, cx.device, dev_src, src_device, acc->c.bytes(), cx.stream));
     cx.add_raw_inplace(acc->c, tmp);
     cx.sync();
     cx.pool.put(tmp);

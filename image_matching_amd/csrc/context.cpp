@@ -439,9 +439,10 @@ void Context::adopt_keys(Context &src) {
     d_rotpack = src.d_rotpack;
     rotptrs_packed = src.rotptrs_packed;
     keys_borrowed = true;
-    HIP_CHECK(hipMemcpy((void *)d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)prm.dim, hipMemcpyDeviceToDevice));
-    HIP_CHECK(hipMemcpy(d_rotgalois, src.d_rotgalois, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice));
-    HIP_CHECK(hipMemcpy(d_rotginv, src.d_rotginv, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpyAsync((void *)d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)prm.dim, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_rotgalois, src.d_rotgalois, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_rotginv, src.d_rotginv, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice, stream));
+    sync();
     rotptrs_valid = true;
 }
 u64 *Context::eval_key_storage(int rot) {

@@ -61,10 +61,13 @@ std::vector<uint32_t> active(const hydia_group *g) {
         if (g->blk_hi[r] > g->blk_lo[r]) a.push_back(r);
     return a;
 }
+// Enqueued on the DESTINATION context's stream, so everything that context launches afterwards is ordered behind the copy (a
+// plain device-to-device hipMemcpy is asynchronous to the host and runs on the null stream, which the contexts' non-blocking
+// streams do not wait for).  The source must be complete (its context synchronised) and stay alive until dst.sync().
 void copy_between(Context &dst, u64 *d, Context &src, const u64 *s, size_t bytes) {
     (void)hipSetDevice(dst.device);
-    if (dst.device == src.device) HIP_CHECK(hipMemcpy(d, s, bytes, hipMemcpyDeviceToDevice));
-    else HIP_CHECK(hipMemcpyPeer(d, dst.device, s, src.device, bytes));
+    if (dst.device == src.device) HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst.stream));
+    else HIP_CHECK(hipMemcpyPeerAsync(d, dst.device, s, src.device, bytes, dst.stream));
 }
 // the query enters on shard 0; every other active shard gets its own copy
 std::vector<Ct> broadcast_query(hydia_group *g, const std::vector<uint32_t> &act, const Ct &q) {
@@ -81,6 +84,7 @@ std::vector<Ct> broadcast_query(hydia_group *g, const std::vector<uint32_t> &act
         cr.sync_all();
         qs[r] = Ct(&cr, q.X, q.npoly, q.nl, q.scale);
         copy_between(cr, qs[r].d, c0, q.d, q.bytes());
+        cr.sync();  // the caller may free or overwrite the query as soon as the scenario call returns
     }
     return qs;
 }
@@ -102,6 +106,8 @@ Ct gather_blocks(hydia_group *g, const std::vector<uint32_t> &act, std::vector<C
             throw std::runtime_error("hydia: shard result shape mismatch");
         copy_between(c0, out.d + g->blk_lo[r] * out.ct_elems(), g->shard[r]->cx, p.d, p.bytes());
     }
+    (void)hipSetDevice(c0.device);
+    c0.sync();  // the shard-local sources are released next
     return out;
 }
 Ct compact(Context &cx, Ct &&c) { return (c.view || !c.compact()) ? cx.clone(c) : std::move(c); }
@@ -218,7 +224,9 @@ int hydia_group_keygen(hydia_group *g, const uint8_t seed[32]) {
             src.sync_all();
             cx.rotptrs_packed = src.rotptrs_packed;
             cx.d_rotpack = src.d_rotpack;
-            HIP_CHECK(hipMemcpy((void *)cx.d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)cx.prm.dim, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpyAsync((void *)cx.d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)cx.prm.dim,
+                                     hipMemcpyDeviceToDevice, cx.stream));
+            cx.sync();
         } else {
             cx.adopt_keys(src);
         }
@@ -286,8 +294,7 @@ int hydia_group_membership_scenario(hydia_group *g, const hydia_ct *query, hydia
         acc = Ct(&c0, 1, f.npoly, f.nl, f.scale);
         u64 *tmp = c0.pool.get(acc.bytes());
         bool first = true;
-        for (uint32_t r : act) {
-            c0.sync();
+        for (uint32_t r : act) {  // copy and integer add are both ordered on shard 0's stream: tmp is reused safely
             copy_between(c0, first ? acc.d : tmp, g->shard[r]->cx, part[r].d, acc.bytes());
             if (!first) c0.add_raw_inplace(acc, tmp);
             first = false;

@@ -38,11 +38,13 @@ def single_context_results(im, prm, n, db, planted, query, kseed=31, dseed=8, qs
     receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
     q = receiver.encryptQuery(query, seed=qseed, nonce=9)
     idx = sender.indexScenario(q)
-    assert receiver.decryptIndex(idx) == sorted(planted)
-    out = dict(q=q.export(), qscale=q.shape()[3], sim=sender.computeSimilarity(q).export(), idx=idx.export(),
-               mem=sender.membershipScenario(q).export(), normalised=a,
-               db_cts={t: cc.db_export_ct(t) for t in (0, cc.dim + 1, cc.db_stats()[1] - 1)})
-    del q, idx
+    found = receiver.decryptIndex(idx)  # (small vector_dim: a random row may legitimately clear 0.44)
+    assert set(planted) <= set(found) and (cc.dim < 512 or found == sorted(planted))
+    mem = sender.membershipScenario(q)
+    out = dict(found=found, member=receiver.decryptMembership(mem), q=q.export(), qscale=q.shape()[3], sim=sender.computeSimilarity(q).export(), idx=idx.export(),
+               mem=mem.export(), normalised=a,
+               db_cts={t: cc.db_export_ct(t) for t in sorted({0, min(cc.dim + 1, cc.db_stats()[1] - 1), cc.db_stats()[1] - 1})})
+    del q, idx, mem
     cc.close()
     return out
 
@@ -70,10 +72,10 @@ def check_group(im, prm, devices, n, db, planted, query, want):
     assert np.array_equal(sender.computeSimilarity(q).export(), want["sim"])
     idx = sender.indexScenario(q)
     assert np.array_equal(idx.export(), want["idx"])          # global block order
-    assert receiver.decryptIndex(idx) == sorted(planted)       # global indices
+    assert receiver.decryptIndex(idx) == want["found"]         # global indices
     mem = sender.membershipScenario(q)
     assert np.array_equal(mem.export(), want["mem"])           # add-many -> integer sum -> mod q -> EvalSum
-    assert receiver.decryptMembership(mem) == (len(planted) > 0)
+    assert receiver.decryptMembership(mem) == want["member"] and (want["member"] or not planted)
     del q, idx, mem
     grp.close()
 
@@ -130,7 +132,7 @@ receiver = im.DiagonalReceiver(cc, n)
 q = receiver.encryptQuery(np.ones(64), seed=2, nonce=9) if rank == 0 else None
 sim, idx, mem = sender.computeSimilarity(q), sender.indexScenario(q), sender.membershipScenario(q)
 if rank == 0:
-    assert receiver.decryptIndex(idx) == planted and receiver.decryptMembership(mem) is True
+    assert set(planted) <= set(receiver.decryptIndex(idx)) and receiver.decryptMembership(mem) is True
     np.savez(sys.argv[3], sim=sim.export(), idx=idx.export(), mem=mem.export())
 dist.barrier()
 dist.destroy_process_group()
@@ -172,7 +174,7 @@ def test_rekey_refreshes_loop_a_keys(im):
     n = 1500
     db = make_db(n, 64, [3], 1)
 
-    def run(cc):
+    def run(cc):  # noqa: E306
         im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=8)
         q = im.DiagonalReceiver(cc, n).encryptQuery(np.ones(64), seed=2, nonce=9)
         s = im.DiagonalSender(cc, n)
@@ -276,7 +278,7 @@ def test_db_save_load_round_trip(im, tmp_path):
     assert c2.db_stats() == stats
     q2 = c2.import_ct(q.export(), q.shape()[3])
     assert np.array_equal(im.DiagonalSender(c2, n).indexScenario(q2).export(), want)
-    assert im.DiagonalReceiver(c2, n).decryptIndex(im.DiagonalSender(c2, n).indexScenario(q2)) == planted
+    assert set(planted) <= set(im.DiagonalReceiver(c2, n).decryptIndex(im.DiagonalSender(c2, n).indexScenario(q2)))
     c3 = im.Context(im.default_params(log_n=12, vector_dim=64), 0)
     with pytest.raises(im.HydiaError):
         c3.db_load(path)
