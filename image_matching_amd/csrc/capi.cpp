@@ -622,6 +622,38 @@ int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs) {
 }
 
 // ------------------------------------------------------------------ measurement
+/* transform `polys` polynomials x limbs [first_mod, first_mod + n_mods) of pooled scratch memory `iters` times (in place; the
+ * data is whatever the pool holds — cost is data independent) and report the HIP-event time per iteration */
+int hydia_bench_ntt(hydia_ctx *ctx, uint32_t polys, uint32_t first_mod, uint32_t n_mods, int inverse, uint32_t iters, double *ms_per_iter) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && ms_per_iter && polys >= 1 && n_mods >= 1 && iters >= 1 && (int)(first_mod + n_mods) <= ctx->cx.nT, "bad argument");
+    Context &cx = ctx->cx;
+    const size_t outer = (size_t)n_mods * cx.N;
+    u64 *buf = cx.pool.get((size_t)polys * outer * sizeof(u64));
+    HIP_CHECK(hipMemsetAsync(buf, 0, (size_t)polys * outer * sizeof(u64), cx.stream));
+    const LimbSel s = cx.sel_range((int)first_mod, (int)(first_mod + n_mods));
+    auto once = [&] {
+        if (inverse) cx.ntt_inv(buf, buf, outer, outer, (int)polys, s, cx.scale_ninv(s));
+        else cx.ntt_fwd(buf, outer, (int)polys, s);
+    };
+    once();
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, cx.stream));
+    for (uint32_t i = 0; i < iters; i++) once();
+    HIP_CHECK(hipEventRecord(b, cx.stream));
+    HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    cx.pool.put(buf);
+    *ms_per_iter = ms / iters;
+    return HYDIA_OK;
+    API_END
+}
 int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64_t *launches) {
     API_BEGIN
     use_device(ctx);

@@ -327,10 +327,23 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
         HIP_CHECK(hipMalloc((void **)&d_itwf, 2 * tb));
         HIP_CHECK(hipMemcpy(d_twf, fr.data(), 2 * tb, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_itwf, ifr.data(), 2 * tb, hipMemcpyHostToDevice));
+        // the same twiddles alone (w / q is then formed as w * (1/q) in the kernel: one multiply for half the bytes per load)
+        std::vector<double> dr((size_t)nT * N), idr((size_t)nT * N);
+        for (size_t i = 0; i < (size_t)nT * N; i++) {
+            dr[i] = (double)tw[i];
+            idr[i] = (double)itw[i];
+        }
+        HIP_CHECK(hipMalloc((void **)&d_twd, tb));
+        HIP_CHECK(hipMalloc((void **)&d_itwd, tb));
+        HIP_CHECK(hipMemcpy(d_twd, dr.data(), tb, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_itwd, idr.data(), tb, hipMemcpyHostToDevice));
     }
     tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod, (const ulonglong2 *)d_twp, (const ulonglong2 *)d_itwp,
-                     (const ulonglong2 *)d_twf, (const ulonglong2 *)d_itwf};
+                     (const ulonglong2 *)d_twf, (const ulonglong2 *)d_itwf, (const double *)d_twd, (const double *)d_itwd, 0u};
     if (getenv("HYDIA_NTT_INT")) tabs.twf = tabs.itwf = nullptr;  // A/B switch: integer butterflies for every limb
+    tabs.fp_mask = 0;
+    for (int m = 0; m < nT; m++)
+        if (tabs.twf != nullptr && mod[m].ks + 2 <= 47) tabs.fp_mask |= 1u << m;
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
     fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
@@ -362,7 +375,7 @@ Context::~Context() {
             for (void *p : {(void *)kv.second.d, (void *)kv.second.d_cell, (void *)kv.second.d_gal})
                 if (p) (void)hipFree(p);
     if (keys_borrowed) d_rotpack = nullptr, d_sk = nullptr, d_pk = nullptr;
-    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp, (void *)d_twf, (void *)d_itwf,
+    for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp, (void *)d_twf, (void *)d_itwf, (void *)d_twd, (void *)d_itwd,
                     (void *)d_rotptrs, (void *)d_rotpack,
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);

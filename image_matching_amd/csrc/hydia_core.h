@@ -113,7 +113,7 @@ struct Context : HostParams {
 
     // device tables
     ModC *d_mod = nullptr;
-    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr, *d_twp = nullptr, *d_itwp = nullptr, *d_twf = nullptr, *d_itwf = nullptr;
+    u64 *d_tw = nullptr, *d_tw_sh = nullptr, *d_itw = nullptr, *d_itw_sh = nullptr, *d_twp = nullptr, *d_itwp = nullptr, *d_twf = nullptr, *d_itwf = nullptr, *d_twd = nullptr, *d_itwd = nullptr;
     NttTables tabs{};
 
     // evaluation keys resident in HBM: [dnum][2][nT][N]; each carries a one-element device cell holding its own

@@ -19,6 +19,8 @@ struct NttTables {
     const ModC *mod;          // [nT]
     const ulonglong2 *twp, *itwp;  // the same tables interleaved as (w, w_shoup) pairs: one 16-byte load per twiddle
     const ulonglong2 *twf, *itwf;  // bit patterns of double pairs (w, w / q) for the FP64 path of the <= 47-bit primes
+    const double *twd, *itwd;      // [nT][N] the twiddles alone as doubles (8 bytes each): the one-pass kernel's per-lane twiddle loads
+    unsigned fp_mask;              // host copy of the kernels' own rule: bit m set <=> modulus m takes the FP64 path
 };
 
 // base conversion table: out[t] = sum_s y[s] * f[s][t] mod q_{dst t}

@@ -61,6 +61,9 @@ struct FpA {
     double q, qinv;
     DEV FpA(const ModC &M) : q((double)M.q), qinv(1.0 / (double)M.q) {}
     DEV static TW tw(const ulonglong2 b) { return make_double2(__longlong_as_double((long long)b.x), __longlong_as_double((long long)b.y)); }
+    // twiddle given alone: w / q as w * (1/q).  The quotient estimate of mulmod may then be off by one more in rare cases: the result
+    // stays an exact representative of a*w (|r| <= ~1.3 q instead of 0.75 q), which the transforms' headroom (< 2^52) absorbs
+    DEV TW tw8(const double wv) const { return make_double2(wv, wv * qinv); }
     // integer <-> double without the emulated 64-bit conversions: for 0 <= x < 2^52 the bit pattern 0x433.. | x IS the double 2^52 + x
     DEV static double u2d(u64 x) { return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0; }
     DEV static u64 d2u(double r) { return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull; }  // r integral in [0, 2^52)
@@ -198,11 +201,11 @@ DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u6
 // grid (8 column tiles, X*sel.n), 256 threads: col = t&31, g = t>>5.  Phase A rows g+8k (k<16), phase B rows 8h+l.
 template <bool INV, int LD>
 __global__ __launch_bounds__(256) void k_ntt15_p1(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
-                                                  size_t dso, LimbSel sel, ScaleSel scale, NttLoad ld) {
+                                                  size_t dso, LimbSel sel, int slot0, int nsl, ScaleSel scale, NttLoad ld) {
     constexpr int N = 32768;
     __shared__ u64 lds[128 * 32];
     __shared__ ulonglong2 ltw[128];
-    const int y = blockIdx.y, x = y / sel.n, slot = y - x * sel.n, m = sel.mod[slot];
+    const int y = blockIdx.y, x = y / nsl, slot = slot0 + (y - x * nsl), m = sel.mod[slot];  // slots [slot0, slot0 + nsl) of sel
     const ModC M = T.mod[m];
     const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
     const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
@@ -551,11 +554,11 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 // grid (16 chunks of 2048, (X/NP)*sel.n)
 template <bool INV, int NP, int ST>
 __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
-                                                  size_t dso, LimbSel sel, NttStore stp) {
+                                                  size_t dso, LimbSel sel, int slot0, int nsl, NttStore stp) {
     constexpr int N = 32768;
     __shared__ u64 lds[NP][8 * 288];
     const int y = blockIdx.y;
-    const int xp = y / sel.n, slot = y - xp * sel.n, m = sel.mod[slot];
+    const int xp = y / nsl, slot = slot0 + (y - xp * nsl), m = sel.mod[slot];
     const ModC M = T.mod[m];
     const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
     const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
@@ -596,6 +599,286 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__r
     else p2_body<IntA, false, NP, 4>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
 }
 
+
+// ------------------------------------------------------------------------------------------------ one-pass transform (FP64 limbs)
+// ONE HBM round trip per limb-polynomial instead of two: a 1024-thread workgroup keeps all 2^15 coefficients of one limb in
+// registers (32 exact-integer doubles per lane) and runs the 15 stages as four register phases; LDS (132 KiB, two half-size
+// rounds per exchange) only transposes between them.  With index bits A = 14..10, B = 9..5, C = 4..2, D = 1..0:
+//   P1 stages 0-4    thread = (B, C, D)            registers = A     strided global access (stride 1024: coalesced), wave-uniform twiddles
+//   P2 stages 5-9    thread = (A, C, D)            registers = B     31 twiddle pairs per thread that depend on A only
+//   P3 stages 10-12  thread = (A, B)               registers = (C,D) radix-8 over C for the 4 values of D: 7 twiddle pairs
+//   P4 stages 13-14  thread = bits 11..2           registers = (bits 14..12, D): eight groups of 4 consecutive coefficients, so
+//                    global access at this end is 32 contiguous bytes per lane, lanes contiguous (the fused epilogues' operands too)
+// The forward transform enters at P1 and leaves at P4 (+ the pass-2 epilogues, unchanged); the inverse runs P4' .. P1' with
+// Gentleman-Sande butterflies and re-centres so that at most four stages run between reductions.  Same butterflies on the same
+// operands as the two-pass path, so results are bit-identical.  Exchanges (X1: A<->B among threads with equal (C,D); X2: B<->(C,D)
+// inside one A; X3: (A,B)<->P4 layout) are ds_write_b64 / ds_read_b64 on images whose row strides (1024, 33, 33 elements) keep
+// every 16-lane write group and 32-lane read group on distinct banks.
+constexpr int OP_LDS_ELEMS = 512 * 33;
+
+// An index the compiler cannot see through: loads addressed with it cannot be hoisted above this point.  (The twiddle tables are
+// const __restrict__, so the scheduler otherwise starts a later phase's twiddle loads phases early — 48 registers held across the
+// exchanges, paid for with spills.)
+DEV int op_pin(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+DEV FpA::TW op_tw(const FpA &, const ulonglong2 b) { return FpA::tw(b); }
+DEV FpA::TW op_tw(const FpA &ar, const double wv) { return ar.tw8(wv); }
+template <bool INV, class TWP>
+DEV void op_stage_set(const FpA &ar, double (&v)[32], const TWP *__restrict__ tw, int base_shift, int hi, int nst, int first_bit) {
+    // nst stages over register-index bits first_bit, first_bit-1, ...: stage s pairs (k, k + h), h = 1 << (first_bit - s),
+    // twiddle tw[(base << s) + (hi << s) + (k >> (first_bit + 1 - s))] with base = 1 << base_shift
+#pragma unroll
+    for (int ss = 0; ss < nst; ss++) {
+        const int s = INV ? nst - 1 - ss : ss;
+        const int h = 1 << (first_bit - s);
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            if (!(k & h)) {
+                const FpA::TW W = op_tw(ar, tw[(1 << (base_shift + s)) + (hi << s) + (k >> (first_bit + 1 - s))]);
+                if (INV) ar.gs(v[k], v[k + h], W);
+                else ar.ct(v[k], v[k + h], W);
+            }
+    }
+}
+
+// P2's twiddles depend on A only and a wave holds exactly two values of A (lanes 0-31 / 32-63): both candidates are fetched with
+// scalar loads (wave-uniform addresses) and selected per lane half — 4 v_cndmask instead of a 16-byte vector load per twiddle,
+// which would occupy the texture-address path for 16 cycles each
+template <bool INV>
+DEV void op_stage_set_p2(const FpA &ar, double (&v)[32], const ulonglong2 *__restrict__ tw, int A0, bool upper) {
+#pragma unroll
+    for (int ss = 0; ss < 5; ss++) {
+        const int s = INV ? 4 - ss : ss;
+        const int h = 16 >> s;
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            if (!(k & h)) {
+                const ulonglong2 b0 = tw[(32 << s) + (A0 << s) + (k >> (5 - s))], b1 = tw[(32 << s) + ((A0 + 1) << s) + (k >> (5 - s))];
+                const FpA::TW W = FpA::tw(make_ulonglong2(upper ? b1.x : b0.x, upper ? b1.y : b0.y));
+                if (INV) ar.gs(v[k], v[k + h], W);
+                else ar.ct(v[k], v[k + h], W);
+            }
+        if (INV && ss == 2) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) ar.recentre(v[k]);
+        }
+    }
+}
+
+// raw operand of the first register phase and its conversion to a canonical residue (the fused prologues of p1_load, split so that
+// the NEXT item's loads can be issued before the current item's last phase)
+template <int LD>
+DEV u64 op_raw_load(const NttLoad &ld, const u64 *s, int x, size_t idx) {
+    return LD == 2 ? ld.y[(size_t)x * ld.y_outer + idx] : s[idx];
+}
+template <int LD>
+DEV u64 op_raw_to_canon(const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, u64 v) {
+    if (LD != 2) return v;
+    const u64 ql = mod[ld.l].q;  // rescale spread: centred residue of the dropped limb's coefficient
+    return v > (ql >> 1) ? negmod(reduce64(ql - v, M), M.q) : reduce64(v, M);
+}
+
+// One workgroup (1024 threads) per item = (limb slot, polynomial), slot-major, so that concurrently resident workgroups share a
+// limb's twiddle table in L2.  (A persistent variant that walks items and prefetches the next item's operands before the last
+// register phase was built and measured: the register allocator spills 300-900 bytes per lane inside the item loop and the
+// transform gets 1.6x SLOWER — profiles/r02/ntt_one_pass.md.)
+template <bool INV, int LD, int ST>
+__global__ __launch_bounds__(1024) void k_ntt15_1p(NttTables T, const ulonglong2 *__restrict__ tw_pairs, const double *__restrict__ tw_single,
+                                                   const ModC *__restrict__ modc, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
+                                                   size_t dso, LimbSel sel, int slot0, int X, int nitems, ScaleSel scale, NttLoad ld, NttStore stp) {
+    // tw_pairs / tw_single / modc are the tables of T again, as __restrict__ kernel parameters: inside the item loop only loads the
+    // compiler knows cannot alias the loop's stores stay scalar (s_load) — through the struct they turn into per-lane vector loads
+    constexpr int N = 32768;
+    extern __shared__ u64 lds[];
+    const int t = threadIdx.x;
+    const bool lo = t < 512;            // wave-uniform: waves 0-7 / 8-15
+    const int A = t >> 5, cd = t & 31;  // P2 / P3 thread coordinates (P3: t = (A, B))
+    const int Ah = A & 15;
+    const int A0 = __builtin_amdgcn_readfirstlane(t >> 6) << 1;  // the wave's first A (wave-uniform)
+    const bool upperA = (t & 32) != 0;
+    const int rd = (t >> 3) * 33 + (t & 7) * 4;  // P4 layout inside the X3 image
+    const int item = blockIdx.x;
+    if (item >= nitems) return;
+    {
+        const int sl = item / X, xp = item - sl * X, slot = slot0 + sl, m = sel.mod[slot];
+        const ModC M = modc[m];
+        const FpA ar(M);
+        const ulonglong2 *__restrict__ tw = tw_pairs + (size_t)m * N;  // wave-uniform twiddles (scalar loads): pairs
+        const double *__restrict__ twd = tw_single + (size_t)m * N;    // per-lane twiddles: 8 bytes each
+        u64 *d = dst + (size_t)xp * dso + (size_t)slot * N;
+        const u64 *s = src + (size_t)xp * so + (size_t)slot * N;
+        double v[32], w[32];
+        if (!INV) {
+            // ---- P1
+#pragma unroll
+            for (int k = 0; k < 32; k++) v[k] = ar.from_canon(op_raw_to_canon<LD>(ld, modc, M, op_raw_load<LD>(ld, s, xp, (size_t)k * 1024 + t)));
+            op_stage_set<false>(ar, v, tw, 0, 0, 5, 4);
+            // ---- X1: element (a, b, cd) at a*1024 + b*32 + cd; halves of a
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[k * 1024 + t] = FpA::to_bits(v[k]);
+            __syncthreads();
+            if (lo) {
+#pragma unroll
+                for (int b = 0; b < 32; b++) w[b] = FpA::from_bits(lds[Ah * 1024 + b * 32 + cd]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[k * 1024 + t] = FpA::to_bits(v[16 + k]);
+            __syncthreads();
+            if (!lo) {
+#pragma unroll
+                for (int b = 0; b < 32; b++) w[b] = FpA::from_bits(lds[Ah * 1024 + b * 32 + cd]);
+            }
+            // ---- P2
+            op_stage_set_p2<false>(ar, w, tw, A0, upperA);
+            // ---- X2 (inside one A): element (A, b, cd) at ((A & 15) * 32 + b) * 33 + cd; halves of A = halves of the waves.  The
+            // exchange is IN PLACE in w (a wave is either writer+reader of a round or idle in it), so 32 values are live, not 64
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int b = 0; b < 32; b++) lds[(Ah * 32 + b) * 33 + cd] = FpA::to_bits(w[b]);
+                }
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int c = 0; c < 32; c++) w[c] = FpA::from_bits(lds[(Ah * 32 + cd) * 33 + c]);  // now thread (A, B = cd)
+                }
+            }
+            // ---- P3: t = (A, B); registers (C, D); stages 10-12 over C = register bits 4..2
+            op_stage_set<false>(ar, w, twd, 10, op_pin(t), 3, 4);
+            // ---- X3 + P4: thread t = index bits 11..2; group f = bits 14..12; element i at ((i >> 5) & 511) * 33 + (i & 31)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int c = 0; c < 32; c++) lds[(t & 511) * 33 + c] = FpA::to_bits(w[c]);
+                }
+                __syncthreads();
+                // the round's twiddles, then (last round) the NEXT item's operands: every register value of this item now sits
+                // in LDS, and vector loads return in issue order, so the twiddles do not wait behind the prefetch
+                double W13[4], W14a[4], W14b[4];
+                const int tp = op_pin(t);
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    const int gi = (4 * h + f) * 1024 + tp;
+                    const double2 w14 = *reinterpret_cast<const double2 *>(twd + 16384 + 2 * gi);
+                    W13[f] = twd[8192 + gi];
+                    W14a[f] = w14.x;
+                    W14b[f] = w14.y;
+                }
+                P2Pre pre = {};
+                if (ST != 0) pre = p2_prefetch<ST>(stp, xp, slot, (unsigned)((4 * h) * 4096 + 4 * t));
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    const int gi = (4 * h + f) * 1024 + t;
+                    P2Pre nxt = {};
+                    if (ST != 0 && f < 3) nxt = p2_prefetch<ST>(stp, xp, slot, (unsigned)(4 * (gi + 1024)));
+                    // one group at a time out of LDS: the other half's 32 values are still waiting in registers
+                    double c0 = FpA::from_bits(lds[f * 128 * 33 + rd]), c1 = FpA::from_bits(lds[f * 128 * 33 + rd + 1]),
+                           c2 = FpA::from_bits(lds[f * 128 * 33 + rd + 2]), c3 = FpA::from_bits(lds[f * 128 * 33 + rd + 3]);
+                    const FpA::TW T13 = ar.tw8(W13[f]);
+                    ar.ct(c0, c2, T13);
+                    ar.ct(c1, c3, T13);
+                    ar.ct(c0, c1, ar.tw8(W14a[f]));
+                    ar.ct(c2, c3, ar.tw8(W14b[f]));
+                    const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
+                    if (ST == 0) {
+                        *reinterpret_cast<ulonglong2 *>(d + 4 * gi) = make_ulonglong2(vv[0], vv[1]);
+                        *reinterpret_cast<ulonglong2 *>(d + 4 * gi + 2) = make_ulonglong2(vv[2], vv[3]);
+                    } else {
+                        p2_finish<ST>(stp, M, xp, slot, (unsigned)(4 * gi), vv, pre);
+                        pre = nxt;
+                    }
+                }
+            }
+        } else {
+            // ---- P4': eight groups of 4 consecutive coefficients; strides 1, 2
+            double x[8][4];
+            const int tq = op_pin(t);
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                const int gi = f * 1024 + tq;
+                const ulonglong2 i0 = *reinterpret_cast<const ulonglong2 *>(s + 4 * gi), i1 = *reinterpret_cast<const ulonglong2 *>(s + 4 * gi + 2);
+                const double2 w14 = *reinterpret_cast<const double2 *>(twd + 16384 + 2 * gi);
+                const FpA::TW W13 = ar.tw8(twd[8192 + gi]), W14a = ar.tw8(w14.x), W14b = ar.tw8(w14.y);
+                double c0 = ar.from_canon(i0.x), c1 = ar.from_canon(i0.y), c2 = ar.from_canon(i1.x), c3 = ar.from_canon(i1.y);
+                ar.gs(c0, c1, W14a);
+                ar.gs(c2, c3, W14b);
+                ar.gs(c0, c2, W13);
+                ar.gs(c1, c3, W13);
+                ar.recentre(c0); ar.recentre(c1); ar.recentre(c2); ar.recentre(c3);
+                x[f][0] = c0; x[f][1] = c1; x[f][2] = c2; x[f][3] = c3;
+            }
+            // ---- X3': P4 layout -> thread (A, B) with registers (C, D)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (h) __syncthreads();
+#pragma unroll
+                for (int f = 0; f < 4; f++)
+#pragma unroll
+                    for (int D = 0; D < 4; D++) lds[f * 128 * 33 + rd + D] = FpA::to_bits(x[4 * h + f][D]);
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int c = 0; c < 32; c++) v[c] = FpA::from_bits(lds[(t & 511) * 33 + c]);
+                }
+            }
+            // ---- P3': strides 4, 8, 16
+            op_stage_set<true>(ar, v, twd, 10, op_pin(t), 3, 4);
+#pragma unroll
+            for (int c = 0; c < 32; c++) ar.recentre(v[c]);
+            // ---- X2' (inside one A, in place): thread (A, B = cd) registers (C, D) -> thread (A, (C,D) = cd) registers B
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int c = 0; c < 32; c++) lds[(Ah * 32 + cd) * 33 + c] = FpA::to_bits(v[c]);
+                }
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int b = 0; b < 32; b++) v[b] = FpA::from_bits(lds[(Ah * 32 + b) * 33 + cd]);
+                }
+            }
+            // ---- P2': strides 32 .. 512 (three stages, re-centre, two stages)
+            op_stage_set_p2<true>(ar, v, tw, A0, upperA);
+            // ---- X1': thread (A, cd) registers B -> thread (B, cd) registers A; halves of A = halves of the waves on the write side
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                __syncthreads();
+                if (lo == (h == 0)) {
+#pragma unroll
+                    for (int b = 0; b < 32; b++) lds[Ah * 1024 + b * 32 + cd] = FpA::to_bits(v[b]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; k++) w[16 * h + k] = FpA::from_bits(lds[k * 1024 + t]);
+            }
+            // ---- P1': strides 1024 .. 16384 (two stages, re-centre, three stages), scale, store
+#pragma unroll
+            for (int ss = 0; ss < 5; ss++) {
+                const int st5 = 4 - ss, h = 16 >> st5;
+#pragma unroll
+                for (int k = 0; k < 32; k++)
+                    if (!(k & h)) ar.gs(w[k], w[k + h], FpA::tw(tw[(1 << st5) + (k >> (5 - st5))]));
+                if (ss == 1) {
+#pragma unroll
+                    for (int k = 0; k < 32; k++) ar.recentre(w[k]);
+                }
+            }
+            const u64 sc = scale.s[slot], scs = scale.s_sh[slot];
+#pragma unroll
+            for (int k = 0; k < 32; k++) d[(size_t)k * 1024 + t] = ar.fin_inv(w[k], sc, scs);
+        }
+    }
+}
+
 }  // namespace
 
 namespace hk {
@@ -634,23 +917,78 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     else hipLaunchKernelGGL((k_ntt15_p2_ip<4, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
 }
 
+// ---- launch plumbing.  With the one-pass kernel enabled (HYDIA_NTT_1PASS) a LimbSel is cut into maximal runs of slots whose moduli
+// take the same arithmetic path: FP64 runs go to the one-pass kernel (not for the fused first-pass base conversion, which it does
+// not implement), integer runs — the 60-bit q_0 and the special primes — to the two-pass kernels restricted to that slot range.
+// read per call: tests flip it inside one process.  HYDIA_NTT_1PASS_MIN = smallest number of limb-polynomials in a launch for which
+// the one-pass kernel is used: it needs one whole workgroup of 1024 threads per limb-polynomial, so small batches (the per-query
+// fixed-cost work) fill the GPU better with the two-pass kernels' 24 smaller workgroups per limb-polynomial
+// Measured on MI355X (profiles/r02/ntt_one_pass.md): the one-pass kernel is 1.15x faster than the two passes on plain transforms
+// streamed from HBM, but its fused-epilogue forms are not, and one 2^20 query gets 1.2 ms slower with it — so it is OFF unless
+// HYDIA_NTT_1PASS is set (the parity tests run both).
+static bool one_pass_enabled() { return getenv("HYDIA_NTT_1PASS") != nullptr && getenv("HYDIA_NTT_2PASS") == nullptr; }
+static int one_pass_min_items() {
+    const char *e = getenv("HYDIA_NTT_1PASS_MIN");
+    return e ? atoi(e) : 1024;
+}
+template <class F>
+static void for_slot_runs(const NttTables &T, const LimbSel &sel, bool split, F fn) {
+    if (!split) {
+        fn(0, sel.n, false);
+        return;
+    }
+    for (int s0 = 0; s0 < sel.n;) {
+        const bool fp = (T.fp_mask >> sel.mod[s0]) & 1u;
+        int s1 = s0 + 1;
+        while (s1 < sel.n && (((T.fp_mask >> sel.mod[s1]) & 1u) != 0) == fp) s1++;
+        fn(s0, s1 - s0, fp);
+        s0 = s1;
+    }
+}
+template <bool INV, int LD, int ST>
+static void launch_1p(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel,
+                      int slot0, int nsl, const ScaleSel &scale, const NttLoad &ld, const NttStore &stp) {
+    static bool attr_done = false;  // > 64 KiB of dynamic LDS has to be granted per kernel
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt15_1p<INV, LD, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  OP_LDS_ELEMS * (int)sizeof(u64));
+        attr_done = true;
+    }
+    const int nitems = X * nsl;
+    hipLaunchKernelGGL((k_ntt15_1p<INV, LD, ST>), dim3(nitems), dim3(1024), OP_LDS_ELEMS * sizeof(u64), st, T,
+                       INV ? T.itwf : T.twf, INV ? T.itwd : T.twd, T.mod, src, dst, so, dso, sel, slot0, X, nitems, scale, ld, stp);
+}
 template <int LD>
 static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
-                          const LimbSel &sel, const NttLoad &ld) {
+                          const LimbSel &sel, int slot0, int nsl, const NttLoad &ld) {
     ScaleSel dummy = {};
-    hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, dummy, ld);
+    hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * nsl), dim3(256), 0, st, T, src, dst, so, dso, sel, slot0, nsl, dummy, ld);
 }
 static bool pair_polys() {  // HYDIA_NTT_NP1: one polynomial per workgroup (half the LDS, twice the twiddle loads)
     static const bool v = getenv("HYDIA_NTT_NP1") == nullptr;
     return v;
 }
 template <int ST>
-static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel,
+static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl,
                           const NttStore &stp) {
     if (X % 2 == 0 && pair_polys())
-        hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, stp);
+        hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
     else
-        hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, stp);
+        hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
+}
+template <int LD, int ST>
+static void forward_runs(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel,
+                         const NttLoad &ld, const NttStore &stp) {
+    const bool split = one_pass_enabled() && LD != 1 && T.fp_mask != 0;
+    for_slot_runs(T, sel, split, [&](int s0, int n, bool fp) {
+        if (fp && split && X * n >= one_pass_min_items()) {
+            ScaleSel dummy = {};
+            launch_1p<false, LD, ST>(st, T, src, dst, so, dso, X, sel, s0, n, dummy, ld, stp);
+        } else {
+            launch_p1_fwd<LD>(st, T, src, dst, so, dso, X, sel, s0, n, ld);
+            launch_p2_fwd<ST>(st, T, dst, dso, X, sel, s0, n, stp);
+        }
+    });
 }
 
 // element (x, slot) at base + x*outer + slot*N.  When X is even, pass 2 transforms polynomials 2x', 2x'+1 together.
@@ -658,32 +996,49 @@ void ntt15_forward(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
                    const LimbSel &sel) {
     NttLoad ld{};
     NttStore stp{};
-    launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
-    launch_p2_fwd<0>(st, T, dst, dso, X, sel, stp);
+    forward_runs<0, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);
 }
+// first pass only (the caller's second pass is fused with the key-switching inner product): always the two-pass kernels
 void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel) {
     NttLoad ld{};
-    launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
+    launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, 0, sel.n, ld);
 }
 void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                          const LimbSel &sel, const NttLoad &ld, const NttStore &stp) {
-    if (ld.mode == 1) launch_p1_fwd<1>(st, T, src, dst, so, dso, X, sel, ld);
-    else if (ld.mode == 2) launch_p1_fwd<2>(st, T, src, dst, so, dso, X, sel, ld);
-    else launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, ld);
-    if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, stp);
-    else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, stp);
-    else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, stp);
-    else launch_p2_fwd<0>(st, T, dst, dso, X, sel, stp);
+    if (ld.mode == 1) {  // base conversion inside pass 1 (HYDIA_FUSE_BCONV experiment): two-pass kernels only
+        launch_p1_fwd<1>(st, T, src, dst, so, dso, X, sel, 0, sel.n, ld);
+        if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+        else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+        else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+        else launch_p2_fwd<0>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+        return;
+    }
+    if (ld.mode == 2) {
+        if (stp.mode == 2) forward_runs<2, 2>(st, T, src, dst, so, dso, X, sel, ld, stp);
+        else forward_runs<2, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);
+        return;
+    }
+    if (stp.mode == 1) forward_runs<0, 1>(st, T, src, dst, so, dso, X, sel, ld, stp);
+    else if (stp.mode == 2) forward_runs<0, 2>(st, T, src, dst, so, dso, X, sel, ld, stp);
+    else if (stp.mode == 3) forward_runs<0, 3>(st, T, src, dst, so, dso, X, sel, ld, stp);
+    else forward_runs<0, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);
 }
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                    const LimbSel &sel, const ScaleSel &scale) {
     NttLoad ld{};
     NttStore stp{};
-    if (X % 2 == 0 && pair_polys())
-        hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, stp);
-    else
-        hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, stp);
-    hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, scale, ld);
+    const bool split = one_pass_enabled() && T.fp_mask != 0;
+    for_slot_runs(T, sel, split, [&](int s0, int n, bool fp) {
+        if (fp && split && X * n >= one_pass_min_items()) {
+            launch_1p<true, 0, 0>(st, T, src, dst, so, dso, X, sel, s0, n, scale, ld, stp);
+            return;
+        }
+        if (X % 2 == 0 && pair_polys())
+            hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+        else
+            hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+        hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, s0, n, scale, ld);
+    });
 }
 
 }  // namespace hk

@@ -33,7 +33,8 @@ class _Info(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhydia.so")
+    # HYDIA_LIBPATH: an alternative build of the same library (kernel A/B experiments, tools/ubench)
+    return os.environ.get("HYDIA_LIBPATH") or os.path.join(_HERE, "libhydia.so")
 
 
 def build_library():
@@ -133,6 +134,7 @@ def load_library():
         "hydia_level_reduce": (i32, [vp, vp, u32]),
         "hydia_kernel_time": (i32, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(u64)]),
         "hydia_kernel_time_reset": (i32, [vp]),
+        "hydia_bench_ntt": (i32, [vp, u32, u32, u32, i32, u32, C.POINTER(dbl)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -443,6 +445,11 @@ class Context:
 
     def kernel_time_reset(self):
         _chk(self.L.hydia_kernel_time_reset(self.h))
+
+    def bench_ntt(self, polys, first_mod, n_mods, inverse=False, iters=10):
+        ms = C.c_double()
+        _chk(self.L.hydia_bench_ntt(self.h, polys, first_mod, n_mods, int(inverse), iters, C.byref(ms)))
+        return ms.value
 
     def memory_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -233,6 +233,10 @@ int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs);
  * ("hydia_tensor" = loop B's tensor-accumulate kernel, "ks_inner_product") ---- */
 int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
 int hydia_kernel_time_reset(hydia_ctx *ctx);
+/* NTT microbenchmark on pooled scratch memory: `polys` polynomials x moduli [first_mod, first_mod + n_mods), in place,
+ * HIP-event milliseconds per iteration (tools/bench_ntt.py; 512 KiB algorithmic per limb-transform) */
+int hydia_bench_ntt(hydia_ctx *ctx, uint32_t polys, uint32_t first_mod, uint32_t n_mods, int inverse, uint32_t iters,
+                    double *ms_per_iter);
 
 #ifdef __cplusplus
 }

@@ -214,9 +214,14 @@ def test_reference_dataset_2_10_full_ring(im):
     cc.close()
 
 
-def test_ntt15_pair_path_and_mixed_limbs(im):
+@pytest.mark.parametrize("one_pass", [False, True])
+def test_ntt15_pair_path_and_mixed_limbs(im, monkeypatch, one_pass):
     """Even polynomial counts take the two-polynomials-per-workgroup pass; both arithmetic back ends (60-bit integer,
-    45-bit FP64) must agree with the oracle bit for bit, forward and inverse."""
+    45-bit FP64) must agree with the oracle bit for bit, forward and inverse — through the two-pass kernels and through the
+    one-pass kernel (k_ntt15_1p: 1024-thread workgroup, 32 coefficients per lane, LDS transposes only)."""
+    if one_pass:
+        monkeypatch.setenv("HYDIA_NTT_1PASS", "1")
+        monkeypatch.setenv("HYDIA_NTT_1PASS_MIN", "1")
     P = O.Params()
     cc = make_ctx(im, P)
     rng = np.random.default_rng(15)
@@ -279,6 +284,8 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         {"HYDIA_NTT_INT": "1", "HYDIA_DB_UNPACKED": "1", "HYDIA_KEYS_UNPACKED": "1", "HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1",
          "HYDIA_LANES": "1"},
         {"HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "3"},
+        {"HYDIA_NTT_1PASS": "1", "HYDIA_NTT_1PASS_MIN": "1"},  # the one-pass kernel (one HBM round trip) for every FP64 limb transform
+        {"HYDIA_NTT_1PASS": "1"},  # ... only for launches of at least 1024 limb-polynomials
     ]
     n = 40000
     rng = np.random.default_rng(77)
@@ -287,7 +294,8 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         db[i] = rng.integers(1, 4, size=512)
     results = []
     for env in variants:
-        for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES"):
+        for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
+                  "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
