@@ -622,6 +622,12 @@ int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs) {
 }
 
 // ------------------------------------------------------------------ measurement
+int hydia_byte_ledger(int enable, char *out, size_t cap, size_t *needed) {
+    const size_t n = (out || needed) ? hk::ledger_dump(out, cap) : 0;
+    if (needed) *needed = n;
+    if (enable >= 0) hk::ledger_enable(enable != 0);  // (re)starts or stops the recording; -1 = just read
+    return HYDIA_OK;
+}
 /* transform `polys` polynomials x limbs [first_mod, first_mod + n_mods) of pooled scratch memory `iters` times (in place; the
  * data is whatever the pool holds — cost is data independent) and report the HIP-event time per iteration */
 int hydia_bench_ntt(hydia_ctx *ctx, uint32_t polys, uint32_t first_mod, uint32_t n_mods, int inverse, uint32_t iters, double *ms_per_iter) {

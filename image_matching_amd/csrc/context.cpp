@@ -349,6 +349,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
     merge_rescale = getenv("HYDIA_NO_MERGE_RESCALE") == nullptr;
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
+    fork_products = getenv("HYDIA_NO_FORK") == nullptr;
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)
@@ -380,6 +381,8 @@ Context::~Context() {
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     for (auto e : lane_ev) (void)hipEventDestroy(e);
+    for (auto e : par_ev)
+        if (e) (void)hipEventDestroy(e);
     for (size_t k = 1; k < lane_stream.size(); k++) (void)hipStreamDestroy(lane_stream[k]);
     if (stream) (void)hipStreamDestroy(stream);
 }

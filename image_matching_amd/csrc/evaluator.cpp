@@ -618,7 +618,7 @@ struct LeafGroup {
     std::vector<int> nodes;
     Ct out;  // [leaf][x]
 };
-Ct cheb_eval(Cheb &ch, std::vector<PNode> &tree, std::vector<LeafGroup> &groups, int id) {
+Ct cheb_eval(Cheb &ch, std::vector<PNode> &tree, std::vector<LeafGroup> &groups, int id, bool fork) {
     Context *cx = ch.cx;
     PNode &n = tree[id];
     if (n.leaf) {
@@ -630,15 +630,26 @@ Ct cheb_eval(Cheb &ch, std::vector<PNode> &tree, std::vector<LeafGroup> &groups,
         v.scale = n.target;
         return v;
     }
-    Ct Q = cheb_eval(ch, tree, groups, n.q);
-    Ct R = cheb_eval(ch, tree, groups, n.r);
+    Ct Q, R;
+    if (fork) {  // quotient and remainder subtrees share nothing but the babies and giants they read
+        cx->par2([&] { Q = cheb_eval(ch, tree, groups, n.q, false); }, [&] { R = cheb_eval(ch, tree, groups, n.r, false); });
+    } else {
+        Q = cheb_eval(ch, tree, groups, n.q, false);
+        R = cheb_eval(ch, tree, groups, n.r, false);
+    }
     return mult_add(cx, Q, ch.G[n.gi], R);
 }
-Ct cheb_tree(Cheb &ch, const double *c, int degree, int gi, double target) {
-    Context *cx = ch.cx;
-    std::vector<PNode> tree;
-    const int root = cheb_plan(ch, tree, c, degree, gi, target);
+struct ChebTree {
+    std::vector<PNode> nodes;
     std::vector<LeafGroup> groups;
+    int root = -1;
+};
+// plan (host only: needs the giants' limb counts and scales, i.e. their Ct objects, not their data) + all leaves
+void cheb_leaves(Cheb &ch, ChebTree &tr, const double *c, int degree, int gi, double target) {
+    Context *cx = ch.cx;
+    std::vector<PNode> &tree = tr.nodes;
+    std::vector<LeafGroup> &groups = tr.groups;
+    tr.root = cheb_plan(ch, tree, c, degree, gi, target);
     for (int i = 0; i < (int)tree.size(); i++) {
         if (!tree[i].leaf) continue;
         int g = -1;
@@ -673,8 +684,10 @@ Ct cheb_tree(Cheb &ch, const double *c, int degree, int gi, double target) {
         grp.out = cx->lincomb_multi(terms, coef, c0, S);
         cx->rescale(grp.out);
     }
-    Ct res = cheb_eval(ch, tree, groups, root);
-    if (res.view) res = cx->clone(res);  // a tree that is a single leaf
+}
+Ct cheb_combine(Cheb &ch, ChebTree &tr) {
+    Ct res = cheb_eval(ch, tr.nodes, tr.groups, tr.root, true);
+    if (res.view) res = ch.cx->clone(res);  // a tree that is a single leaf
     return res;
 }
 // interpolation of step-at-delta at the degree+1 Chebyshev nodes (what EvalChebyshevFunction derives)
@@ -707,44 +720,66 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
     ch.T.resize(9);
     ch.T[1] = x.alias(x.nl);
     const int top = std::min(degree, 8);
+    // independent products run as pairs: on one lane for multi-block batches (throughput-bound), on two for a single block
     if (top >= 2) ch.T[2] = cheb_step(this, ch.T[1], ch.T[1], nullptr);
-    if (top >= 3) ch.T[3] = cheb_step(this, ch.T[2], ch.T[1], &ch.T[1]);
-    if (top >= 4) ch.T[4] = cheb_step(this, ch.T[2], ch.T[2], nullptr);
-    if (top >= 5) ch.T[5] = cheb_step(this, ch.T[3], ch.T[2], &ch.T[1]);
-    if (top >= 6) ch.T[6] = cheb_step(this, ch.T[3], ch.T[3], nullptr);
-    if (top >= 7) ch.T[7] = cheb_step(this, ch.T[4], ch.T[3], &ch.T[1]);
-    if (top >= 8) ch.T[8] = cheb_step(this, ch.T[4], ch.T[4], nullptr);
+    par2([&] { if (top >= 3) ch.T[3] = cheb_step(this, ch.T[2], ch.T[1], &ch.T[1]); },
+         [&] { if (top >= 4) ch.T[4] = cheb_step(this, ch.T[2], ch.T[2], nullptr); });
+    par2([&] {
+             if (top >= 5) ch.T[5] = cheb_step(this, ch.T[3], ch.T[2], &ch.T[1]);
+             if (top >= 6) ch.T[6] = cheb_step(this, ch.T[3], ch.T[3], nullptr);
+         },
+         [&] {
+             if (top >= 7) ch.T[7] = cheb_step(this, ch.T[4], ch.T[3], &ch.T[1]);
+             if (top >= 8) ch.T[8] = cheb_step(this, ch.T[4], ch.T[4], nullptr);
+         });
     int gi = -1;
-    if (degree >= 8) {
-        ch.G.push_back(ch.T[8].alias(ch.T[8].nl));
-        gi = 0;
-        while ((8 << (gi + 1)) <= degree) {
-            Ct nx = cheb_step(this, ch.G[gi], ch.G[gi], nullptr);
-            ch.G.push_back(std::move(nx));
-            gi++;
-        }
-    }
-    Ct y = cheb_tree(ch, c.data(), degree, gi, delta);
+    ChebTree tr;
+    // the giants T_16, T_32 (a chain of squarings) next to the Paterson-Stockmeyer leaves (linear in T_1..T_7): the side piece is
+    // enqueued first, so the giants' limb counts and scales are known when the tree is planned
+    par2([&] { cheb_leaves(ch, tr, c.data(), degree, gi, delta); },
+         [&] {
+             if (degree >= 8) {
+                 ch.G.push_back(ch.T[8].alias(ch.T[8].nl));
+                 gi = 0;
+                 while ((8 << (gi + 1)) <= degree) {
+                     Ct nx = cheb_step(this, ch.G[gi], ch.G[gi], nullptr);
+                     ch.G.push_back(std::move(nx));
+                     gi++;
+                 }
+             }
+         });
+    Ct y = cheb_combine(ch, tr);
+    tr.groups.clear();
     ch.G.clear();
     ch.T.clear();
     // f4 in depth 4: (c1 y + c3 y^3) + y^4 (c5 y + c7 y^3) + (c9 y) y^8   (openFHE_wrapper.cpp:158-169, :179)
-    Ct y2 = mult(y, y), y3 = mult(y2, y), y4 = mult(y2, y2), y8 = mult(y4, y4);
+    Ct y2 = mult(y, y), y3, y4, y8;
+    par2([&] { y3 = mult(y2, y); }, [&] { y4 = mult(y2, y2); });
     const int nl = y3.nl;
     Ct yd = y.alias(nl);
     // v at scale Delta; a = v*y^4 fixes the scale the other two summands are steered to.  u is evaluated before a and b
-    // and the sum a + b + u is formed in the rescale epilogues of the two products
-    Ct v = lincomb({&yd, &y3}, {F4[5], F4[7]}, 0.0, delta * (double)q[nl - 1]);
-    rescale(v);
-    v.scale = delta;
-    const double a_scale = (v.scale * y4.scale) / (double)q[std::min(v.nl, y4.nl) - 1];
-    Ct u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, a_scale * (double)q[nl - 1]);
-    rescale(u);
-    u.scale = a_scale;
-    const int lb = std::min(y.nl - 1, y8.nl);
-    const double wt = a_scale * (double)q[lb - 1] / y8.scale;
-    Ct w = lincomb({&y}, {F4[9]}, 0.0, wt * (double)q[y.nl - 1]);
-    rescale(w);
-    w.scale = wt;
+    // and the sum a + b + u is formed in the rescale epilogues of the two products.  y^8 (one more squaring) runs beside the three
+    // linear pieces; its limb count and scale follow from y^4's on the host
+    const int y8_nl = y4.nl - 1;
+    const double y8_scale = (y4.scale * y4.scale) / (double)q[y4.nl - 1];
+    Ct v, u, w;
+    double a_scale = 0;
+    par2([&] {
+             v = lincomb({&yd, &y3}, {F4[5], F4[7]}, 0.0, delta * (double)q[nl - 1]);
+             rescale(v);
+             v.scale = delta;
+             a_scale = (v.scale * y4.scale) / (double)q[std::min(v.nl, y4.nl) - 1];
+             u = lincomb({&yd, &y3}, {F4[1], F4[3]}, 0.0, a_scale * (double)q[nl - 1]);
+             rescale(u);
+             u.scale = a_scale;
+             const int lb = std::min(y.nl - 1, y8_nl);
+             const double wt = a_scale * (double)q[lb - 1] / y8_scale;
+             w = lincomb({&y}, {F4[9]}, 0.0, wt * (double)q[y.nl - 1]);
+             rescale(w);
+             w.scale = wt;
+         },
+         [&] { y8 = mult(y4, y4); });
+    if (y8.nl != y8_nl || y8.scale != y8_scale) throw std::runtime_error("hydia: comparator scale plan out of step");
     Ct au = mult_add(this, v, y4, u);
     Ct a = mult_add(this, w, y8, au);
     a.scale = a_scale;
@@ -771,10 +806,12 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
         Context *c;
         ~LaneGuard() {
             c->set_lane(0);
+            c->side_lane_free = true;
             if (std::uncaught_exceptions() > 0)  // error path: let every lane drain before buffers shared across lanes are released
                 for (auto st : c->lane_stream) (void)hipStreamSynchronize(st);
         }
     } guard{this};
+    side_lane_free = false;  // the lanes are taken by the block split: products inside run in sequence
     HIP_CHECK(hipEventRecord(ev[L], stream));  // acc is ready (everything enqueued on the main stream so far)
     std::vector<Ct> res(L);
     Ct out;

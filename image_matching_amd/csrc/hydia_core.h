@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -109,6 +110,13 @@ struct Context : HostParams {
     std::vector<hipEvent_t> lane_ev;
     void set_lane(int k);
     void sync_all();
+    // Two INDEPENDENT pieces of evaluator work.  On the main lane of a single-lane section (one block: everything is
+    // latency-bound, a launch fills a fraction of the GPU) `side` is enqueued on lane 1 and runs concurrently with `here`;
+    // otherwise they simply run one after the other.  Same arithmetic per ciphertext either way.  Not nestable.
+    template <class F0, class F1>
+    void par2(F0 &&here, F1 &&side);
+    bool side_lane_free = true;   // false inside multi-lane sections and inside par2
+    hipEvent_t par_ev[2] = {nullptr, nullptr};
     Pool pool;
 
     // device tables
@@ -179,6 +187,7 @@ struct Context : HostParams {
     void ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc);
     // ModUp: c [X][nl][N] at stride c_outer -> dig [X][nd][nE][N]
     void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true, bool p1_only = false);
+    bool fork_products = true;  // comparator: independent products of a one-block query on two lanes (HYDIA_NO_FORK)
     bool fuse_ip = true;  // relinearisation: second NTT pass of ModUp fused with the inner product (HYDIA_NO_FUSE_IP)
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
     // keys_packed_nQ > 0: d_keys point at packed keys (hk::key_pack)
@@ -237,6 +246,39 @@ struct Context : HostParams {
     void timer_end(const char *name);
     void timer_collect();
 };
+
+template <class F0, class F1>
+void Context::par2(F0 &&here, F1 &&side) {
+    if (!(side_lane_free && nlanes >= 2 && pool.cur == 0 && fork_products)) {
+        side();
+        here();
+        return;
+    }
+    if (!par_ev[0]) {
+        HIP_CHECK(hipEventCreateWithFlags(&par_ev[0], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&par_ev[1], hipEventDisableTiming));
+    }
+    side_lane_free = false;
+    struct Guard {  // an exception inside either piece must not leave the context on the side lane
+        Context *c;
+        ~Guard() {
+            c->set_lane(0);
+            c->side_lane_free = true;
+            if (std::uncaught_exceptions() > 0)
+                for (auto st : c->lane_stream) (void)hipStreamSynchronize(st);
+        }
+    } guard{this};
+    // blocks the side lane takes from its free list were released on the host before this point, i.e. after their last
+    // consumers were enqueued: waiting for the main lane's position covers them (same discipline as relin_compare_lanes)
+    HIP_CHECK(hipEventRecord(par_ev[0], stream));
+    set_lane(1);
+    HIP_CHECK(hipStreamWaitEvent(stream, par_ev[0], 0));
+    side();
+    HIP_CHECK(hipEventRecord(par_ev[1], stream));
+    set_lane(0);
+    here();
+    HIP_CHECK(hipStreamWaitEvent(stream, par_ev[1], 0));
+}
 
 // host residue of a real constant (value already multiplied by its scale)
 u64 double_to_mod(double v, u64 q);

@@ -108,6 +108,13 @@ struct DbLayout {
 };
 
 namespace hk {
+// ---- byte ledger (measurement): when enabled, every launcher below records the bytes its launch has to move (operands read +
+// results written, each once; shared operands that stay in L2 — key tiles, twiddles, digits of loop A — are not counted) under the
+// kernel's name, so that tools/kernel_rooflines.py can put a GB/s figure next to EVERY kernel of a query
+void ledger_enable(bool on);
+void ledger_add(const char *kernel, double bytes);
+size_t ledger_dump(char *out, size_t cap);  // "kernel\tlaunches\tbytes\n" per line; returns the size needed
+
 DbLayout db_layout(int N, int nQ, int packed);
 void db_pack(hipStream_t st, int N, int nQ, const u64 *plain /* [X][2][nQ][N] */, void *db, int X, int packed);
 void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, int X, int packed);

@@ -14,7 +14,13 @@
 // instruction) of one limb, so modulus constants are wave-uniform.
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
 
 namespace {
 
@@ -583,6 +589,65 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restr
     }
 }
 
+// Loop B for SMALL databases (at most 8 blocks on this GPU): the limb-0 launch of k_hydia_tensor has only 256 x G waves, each
+// walking all `dim` diagonals — latency-bound (0.6 ms at G = 1 for 0.5 GB).  Here KS waves of a workgroup share one
+// (block, tile) and take every KS-th diagonal; the partial sums are reduced modulo q_j through LDS.  Same residues as the
+// one-wave kernel (a sum modulo q does not depend on how it is split).
+template <int KS, bool PK>
+__global__ __launch_bounds__(64 * KS) void k_hydia_tensor_sk(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
+                                                             const unsigned char *__restrict__ db, u64 *__restrict__ acc, int dim,
+                                                             int nl, DbLayout L, int j0) {
+    __shared__ u64 part[KS][6][64];
+    const int j = blockIdx.y + j0, tiles = N / 128;
+    const int tile = blockIdx.x % tiles, g = blockIdx.x / tiles;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ModC M = mod[j];
+    const size_t c = (size_t)tile * 128 + lane * 2;
+    const size_t ps = (size_t)nl * N, cs = 2 * ps;
+    const u64 *ra = rot + (size_t)j * N + c;
+    const unsigned char *da = db + (size_t)g * dim * L.ct_bytes + db_limb_offset(L, N, j) + c * (PK ? 6 : 8);
+    const int kbits = M.ks + 2;
+    const int chunk = (125 - 2 * kbits >= 30) ? dim : (1 << (125 - 2 * kbits));  // products a lazy 128-bit sum can take
+    u128 d0x = 0, d0y = 0, dkx = 0, dky = 0, d2x = 0, d2y = 0;
+    int since = 0;
+    for (int i = wv; i < dim; i += KS) {
+        const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
+        const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs + ps);
+        const ulonglong2 b0 = db_load2<PK, true>(da + (size_t)i * L.ct_bytes);
+        const ulonglong2 b1 = db_load2<PK, true>(da + (size_t)i * L.ct_bytes + L.poly_bytes);
+        d0x += (u128)a0.x * b0.x;
+        d0y += (u128)a0.y * b0.y;
+        d2x += (u128)a1.x * b1.x;
+        d2y += (u128)a1.y * b1.y;
+        dkx += (u128)(a0.x + a1.x) * (b0.x + b1.x);
+        dky += (u128)(a0.y + a1.y) * (b0.y + b1.y);
+        if (++since == chunk) {
+            since = 0;
+            d0x = reduce128(d0x, M); d0y = reduce128(d0y, M);
+            dkx = reduce128(dkx, M); dky = reduce128(dky, M);
+            d2x = reduce128(d2x, M); d2y = reduce128(d2y, M);
+        }
+    }
+    part[wv][0][lane] = reduce128(d0x, M); part[wv][1][lane] = reduce128(d0y, M);
+    part[wv][2][lane] = reduce128(dkx, M); part[wv][3][lane] = reduce128(dky, M);
+    part[wv][4][lane] = reduce128(d2x, M); part[wv][5][lane] = reduce128(d2y, M);
+    __syncthreads();
+    if (wv == 0) {
+        u64 r[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            u64 t = part[0][k][lane];
+            for (int w = 1; w < KS; w++) t = addmod(t, part[w][k][lane], M.q);
+            r[k] = t;
+        }
+        u64 *o = acc + ((size_t)g * 3 * nl + j) * N + c;
+        *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2(r[0], r[1]);
+        *reinterpret_cast<ulonglong2 *>(o + ps) = make_ulonglong2(submod(submod(r[2], r[0], M.q), r[4], M.q), submod(submod(r[3], r[1], M.q), r[5], M.q));
+        *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = make_ulonglong2(r[4], r[5]);
+    }
+}
+
+
 // unpacked [X][2][nQ][N] u64  <->  database layout.  grid (N/512, nQ, X*2)
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_db_repack(int N, int nQ, u64 *__restrict__ plain, unsigned char *__restrict__ db,
@@ -626,6 +691,41 @@ __global__ __launch_bounds__(256) void k_fill_uniform_hash(const ModC *__restric
 // ================================================================================================ launchers
 namespace hk {
 
+// ---- byte ledger
+namespace {
+bool g_ledger_on = false;
+std::mutex g_ledger_mu;
+std::map<std::string, std::pair<long, double>> g_ledger;
+}  // namespace
+void ledger_enable(bool on) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    g_ledger_on = on;
+    g_ledger.clear();
+}
+void ledger_add(const char *kernel, double bytes) {
+    if (!g_ledger_on) return;
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    auto &e = g_ledger[kernel];
+    e.first++;
+    e.second += bytes;
+}
+size_t ledger_dump(char *out, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    std::string t;
+    char line[256];
+    for (auto &kv : g_ledger) {
+        snprintf(line, sizeof line, "%s\t%ld\t%.0f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        t += line;
+    }
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, t.size());
+        memcpy(out, t.data(), n);
+        out[n] = 0;
+    }
+    return t.size() + 1;
+}
+#define LP_BYTES(N) ((double)(N) * 8.0)
+
 static bool use_generic_ntt() {
     static const bool g = getenv("HYDIA_NTT_GENERIC") != nullptr;
     return g;
@@ -649,41 +749,52 @@ void ntt_inverse(hipStream_t st, const NttTables &T, int logN, const u64 *src, u
 }
 void add(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
          int b_ls, int o_ls) {
+    ledger_add("k_addsub", 3.0 * XP * sel.n * LP_BYTES(N));
     hipLaunchKernelGGL(k_addsub<0>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
 }
 void sub(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
          int b_ls, int o_ls) {
+    ledger_add("k_addsub", 3.0 * XP * sel.n * LP_BYTES(N));
     hipLaunchKernelGGL(k_addsub<1>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
 }
 void add_raw(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int XP, const LimbSel &sel, int a_ls,
              int b_ls, int o_ls) {
+    ledger_add("k_addsub", 3.0 * XP * sel.n * LP_BYTES(N));
     hipLaunchKernelGGL(k_addsub<2>, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, b, o, sel, a_ls, b_ls, o_ls);
 }
 void mod_reduce(hipStream_t st, const ModC *mod, int N, u64 *a, int XP, const LimbSel &sel, int a_ls) {
+    ledger_add("k_mod_reduce", 2.0 * XP * sel.n * LP_BYTES(N));
     hipLaunchKernelGGL(k_mod_reduce, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, sel, a_ls);
 }
 void mul_scalar(hipStream_t st, const ModC *mod, int N, const u64 *a, u64 *o, int XP, const LimbSel &sel,
                 const ScaleSel &c, int a_ls, int o_ls) {
+    ledger_add("k_mul_scalar", 2.0 * XP * sel.n * LP_BYTES(N));
     hipLaunchKernelGGL(k_mul_scalar, dim3(N / 512, XP * sel.n), dim3(256), 0, st, mod, N, a, o, sel, c, a_ls, o_ls);
 }
 void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, int X, int npoly, int nl) {
+    ledger_add("k_lincomb", (lc.nterms + 1.0) * X * npoly * nl * LP_BYTES(N));
     hipLaunchKernelGGL(k_lincomb, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, npoly, nl);
 }
 void lincomb_multi(hipStream_t st, const ModC *mod, int N, const LinCombMulti &lc, u64 *o, int X, int npoly, int nl) {
+    ledger_add("k_lincomb_multi", (lc.nterms + (double)lc.K) * X * npoly * nl * LP_BYTES(N));
     hipLaunchKernelGGL(k_lincomb_multi, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, X * npoly, npoly, nl);
 }
 void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl) {
+    ledger_add("k_batch_sum", (X + 1.0) * npoly * nl * LP_BYTES(N));
     hipLaunchKernelGGL(k_batch_sum, dim3(N / 512, nl, npoly), dim3(256), 0, st, mod, N, in, o, X, npoly, nl);
 }
 void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,
                 const ScaleSel &c) {
+    ledger_add("k_add_scalar", 2.0 * X * sel.n * LP_BYTES(N));
     hipLaunchKernelGGL(k_add_scalar, dim3(N / 512, X * sel.n), dim3(256), 0, st, mod, N, a, outer, sel, c);
 }
 void copy_limbs(hipStream_t st, int N, const u64 *src, u64 *dst, size_t so, size_t dso, int X, int nlimbs) {
+    ledger_add("k_copy_limbs", 2.0 * X * nlimbs * LP_BYTES(N));
     hipLaunchKernelGGL(k_copy_limbs, dim3(N / 512, X * nlimbs), dim3(256), 0, st, N, src, dst, so, dso, nlimbs);
 }
 void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls,
             const u64 *c, int c_ls, const ScaleSel *kap) {
+    ledger_add(c ? "k_tensor<true>" : "k_tensor<false>", (c ? 9.0 : 7.0) * X * nl * LP_BYTES(N));  // a0 a1 b0 b1 (c0 c1) in, d0 d1 d2 out
     if (c)
         hipLaunchKernelGGL(k_tensor<true>, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl, a_ls, b_ls, c, c_ls, *kap);
     else
@@ -692,11 +803,18 @@ void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, 
 }
 void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, u64 *out, size_t oo, int X,
                   const ConvTab &tab, const LimbSel &dsel) {
+    ledger_add("k_base_convert", (double)X * (tab.ns + tab.nt - (tab.skip_hi - tab.skip_lo)) * LP_BYTES(N));  // sources once, every target once
     hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
                    int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl,
                    int acc_rows, int packed_nQ) {
+    {   // keys of X rotations streamed once (one shared key: once in all), digits / own limbs once per x unless shared (dxs == 0), acc out
+        const double keyb = packed_nQ > 0 ? (double)key_packed_bytes(N, packed_nQ, nT, nd) * esel.n / nT : (double)nd * 2 * esel.n * LP_BYTES(N);
+        const double digb = (double)nd * esel.n * LP_BYTES(N);
+        ledger_add(packed_nQ > 0 ? "k_inner_product<true>" : "k_inner_product<false>",
+                   (same_key ? keyb : keyb * X) + (dxs ? digb * X : digb) + 2.0 * X * esel.n * LP_BYTES(N));
+    }
     if (packed_nQ > 0)
         hipLaunchKernelGGL(k_inner_product<true>, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
                            nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n, packed_nQ);
@@ -706,28 +824,34 @@ void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_
 }
 size_t key_packed_bytes(int N, int nQ, int nT, int nd) { return (size_t)nd * 2 * key_set_bytes(N, nQ, nT); }
 void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out) {
+    ledger_add("k_key_pack", (double)nd * 2 * nT * LP_BYTES(N) + (double)key_packed_bytes(N, nQ, nT, nd));
     hipLaunchKernelGGL(k_key_pack, dim3(N / 512, nT, nd * 2), dim3(256), 0, st, N, nQ, nT, key, (unsigned char *)out);
 }
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
                      const u64 *addend, size_t axs, size_t aps, int add_polys, u64 *out, int X, int nl,
                      const ScaleSel &pinv, const unsigned *galois, int same_g) {
+    ledger_add("k_moddown_combine", (3.0 + (addend ? 0.5 * add_polys : 0.0)) * X * 2 * nl * LP_BYTES(1 << logN));
     hipLaunchKernelGGL(k_moddown_combine, dim3((1 << logN) / 256, nl, X * 2), dim3(256), 0, st, mod, logN, acc, acc_limbs,
                        conv, addend, axs, aps, add_polys, out, nl, pinv, galois, same_g);
 }
 void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
                           const ConvTab &tab) {
+    ledger_add("k_moddown_rescale_conv", (double)XP * (nP + 1 + l) * LP_BYTES(N));  // y (nP limbs) + u in, l limbs out
     hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab);
 }
 void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
                        size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl) {
+    ledger_add("k_moddown_last_limb", 3.0 * XP * LP_BYTES(N));
     hipLaunchKernelGGL(k_moddown_last_limb, dim3(N / 512, XP), dim3(256), 0, st, mod, N, acc, acc_limbs, addend, add_x, add_p, u, l,
                        pinv, pinv_sh, dbl);
 }
 void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l) {
+    ledger_add("k_rescale_spread", (1.0 + l) * X * LP_BYTES(N));
     hipLaunchKernelGGL(k_rescale_spread, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, t, tmp, l);
 }
 void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, const u64 *tmp, u64 *out, int X, int l,
                      const ScaleSel &qlinv, int in_ls) {
+    ledger_add("k_rescale_combine", 3.0 * X * l * LP_BYTES(N));
     hipLaunchKernelGGL(k_rescale_combine, dim3(N / 256, l, X), dim3(256), 0, st, mod, N, in, tmp, out, l, qlinv, in_ls);
 }
 template <int BPP, int NW>
@@ -738,9 +862,28 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
     const int xm = (N / 128) % 8 == 0 ? xcd_map : 0;
     const unsigned char *dbb = (const unsigned char *)db;
     const dim3 blk(64 * NW);
+    {   // resident database (6- or 8-byte residues) + rotated queries once + accumulators, split limb 0 / other limbs like the launches
+        const double per_lp6 = (double)N * 6.0, per_lp8 = LP_BYTES(N);
+        const double rot_acc = (double)dim * 2 * per_lp8 + (double)G * 3 * per_lp8;
+        char n0[64], n1[64];
+        snprintf(n0, sizeof n0, "k_hydia_tensor<%d, %d, true, false>", BPP, NW);
+        snprintf(n1, sizeof n1, "k_hydia_tensor<%d, %d, true, true>", BPP, NW);
+        if (L.packed && G <= 8) snprintf(n0, sizeof n0, "k_hydia_tensor_sk<%d, false>", G <= 2 ? 16 : 4);
+        if (L.packed) {
+            ledger_add(n0, (double)G * dim * 2 * per_lp8 + rot_acc);
+            if (nl > 1) ledger_add(n1, (nl - 1) * ((double)G * dim * 2 * per_lp6 + rot_acc));
+        } else {
+            ledger_add(n0, nl * ((double)G * dim * 2 * per_lp8 + rot_acc));
+        }
+    }
     if (L.packed) {  // limb 0 (8-byte residues) and limbs 1.. (6-byte residues) as two launches: no shared register budget
-        hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
-                           Gq, xm, L, 0);
+        if (G <= 2)  // few blocks: 256 x G one-wave workgroups cannot hide the latency of 512 dependent steps -> split the diagonals
+            hipLaunchKernelGGL((k_hydia_tensor_sk<16, false>), dim3((N / 128) * G, 1), dim3(64 * 16), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0);
+        else if (G <= 8)
+            hipLaunchKernelGGL((k_hydia_tensor_sk<4, false>), dim3((N / 128) * G, 1), dim3(64 * 4), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0);
+        else
+            hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
+                               Gq, xm, L, 0);
         if (nl > 1)
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, true>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc,
                                dim, nl, Gq, xm, L, 1);

@@ -897,6 +897,16 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     stp.ip.c2 = c2;
     stp.ip.c2_xs = c2_xs;
     stp.ip.acc = acc;
+    if (nd >= 2) {  // NP pass-1 digits in (+ the limb's own residues), two accumulator rows out; the key tiles are shared by all x (L2)
+        char name[64];
+        snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, true>", nd - 1 > 3 ? 3 : nd - 1);
+        ledger_add(name, ((nd - 1) + 1 + 2.0) * nl * X * 262144.0);
+    }
+    {
+        char name[64];
+        snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, false>", nd > 4 ? 4 : nd);
+        ledger_add(name, (nd + 2.0) * nP * X * 262144.0);
+    }
     // Q limbs: nd - 1 digits are transformed, the limb's own digit is read from c2
     if (nd == 1) {
         LimbSel qs{};
@@ -924,12 +934,16 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
 // the one-pass kernel is used: it needs one whole workgroup of 1024 threads per limb-polynomial, so small batches (the per-query
 // fixed-cost work) fill the GPU better with the two-pass kernels' 24 smaller workgroups per limb-polynomial
 // Measured on MI355X (profiles/r02/ntt_one_pass.md): the one-pass kernel is 1.15x faster than the two passes on plain transforms
-// streamed from HBM, but its fused-epilogue forms are not, and one 2^20 query gets 1.2 ms slower with it — so it is OFF unless
-// HYDIA_NTT_1PASS is set (the parity tests run both).
-static bool one_pass_enabled() { return getenv("HYDIA_NTT_1PASS") != nullptr && getenv("HYDIA_NTT_2PASS") == nullptr; }
-static int one_pass_min_items() {
+// streamed from HBM in launches of thousands of limb-polynomials, slower on small or Infinity-Cache-resident batches and on the
+// fused epilogues; inside a query it loses everywhere it was tried (whole pipeline +1.2 ms at 2^20; loop A's ModDown transforms
+// alone +0.35 ms per query).  So it is OFF by default.  HYDIA_NTT_1PASS = every FP64 transform of at least HYDIA_NTT_1PASS_MIN
+// limb-polynomials (default 1024).  Read per call: the parity tests flip the switches inside one process.
+static bool use_one_pass(bool inv, int ld, int st, int items) {
+    (void)inv;
+    (void)st;
+    if (!getenv("HYDIA_NTT_1PASS") || ld == 1) return false;
     const char *e = getenv("HYDIA_NTT_1PASS_MIN");
-    return e ? atoi(e) : 1024;
+    return items >= (e ? atoi(e) : 1024);
 }
 template <class F>
 static void for_slot_runs(const NttTables &T, const LimbSel &sel, bool split, F fn) {
@@ -955,6 +969,11 @@ static void launch_1p(hipStream_t st, const NttTables &T, const u64 *src, u64 *d
         attr_done = true;
     }
     const int nitems = X * nsl;
+    {
+        char name[64];
+        snprintf(name, sizeof name, "k_ntt15_1p<%s, %d, %d>", INV ? "true" : "false", LD, ST);
+        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * nitems * 262144.0);
+    }
     hipLaunchKernelGGL((k_ntt15_1p<INV, LD, ST>), dim3(nitems), dim3(1024), OP_LDS_ELEMS * sizeof(u64), st, T,
                        INV ? T.itwf : T.twf, INV ? T.itwd : T.twd, T.mod, src, dst, so, dso, sel, slot0, X, nitems, scale, ld, stp);
 }
@@ -962,6 +981,8 @@ template <int LD>
 static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                           const LimbSel &sel, int slot0, int nsl, const NttLoad &ld) {
     ScaleSel dummy = {};
+    ledger_add(LD == 0 ? "k_ntt15_p1<false, 0>" : LD == 1 ? "k_ntt15_p1<false, 1>" : "k_ntt15_p1<false, 2>",
+               (LD == 2 ? 1.0 + 1.0 / (nsl > 0 ? nsl : 1) : 2.0) * X * nsl * 262144.0);  // LD 2 reads ONE dropped limb per polynomial
     hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * nsl), dim3(256), 0, st, T, src, dst, so, dso, sel, slot0, nsl, dummy, ld);
 }
 static bool pair_polys() {  // HYDIA_NTT_NP1: one polynomial per workgroup (half the LDS, twice the twiddle loads)
@@ -971,6 +992,11 @@ static bool pair_polys() {  // HYDIA_NTT_NP1: one polynomial per workgroup (half
 template <int ST>
 static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl,
                           const NttStore &stp) {
+    {   // pass-1 output in, result out, + the epilogue's operands: acc & addend (1), rescale input (2), both + subtrahend (3)
+        char name[64];
+        snprintf(name, sizeof name, "k_ntt15_p2<false, %d, %d>", (X % 2 == 0 && pair_polys()) ? 2 : 1, ST);
+        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * X * nsl * 262144.0);
+    }
     if (X % 2 == 0 && pair_polys())
         hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
     else
@@ -979,9 +1005,9 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
 template <int LD, int ST>
 static void forward_runs(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel,
                          const NttLoad &ld, const NttStore &stp) {
-    const bool split = one_pass_enabled() && LD != 1 && T.fp_mask != 0;
+    const bool split = T.fp_mask != 0 && use_one_pass(false, LD, ST, X * sel.n);
     for_slot_runs(T, sel, split, [&](int s0, int n, bool fp) {
-        if (fp && split && X * n >= one_pass_min_items()) {
+        if (fp && split && use_one_pass(false, LD, ST, X * n)) {
             ScaleSel dummy = {};
             launch_1p<false, LD, ST>(st, T, src, dst, so, dso, X, sel, s0, n, dummy, ld, stp);
         } else {
@@ -1027,12 +1053,14 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
                    const LimbSel &sel, const ScaleSel &scale) {
     NttLoad ld{};
     NttStore stp{};
-    const bool split = one_pass_enabled() && T.fp_mask != 0;
+    const bool split = T.fp_mask != 0 && use_one_pass(true, 0, 0, X * sel.n);
     for_slot_runs(T, sel, split, [&](int s0, int n, bool fp) {
-        if (fp && split && X * n >= one_pass_min_items()) {
+        if (fp && split && use_one_pass(true, 0, 0, X * n)) {
             launch_1p<true, 0, 0>(st, T, src, dst, so, dso, X, sel, s0, n, scale, ld, stp);
             return;
         }
+        ledger_add((X % 2 == 0 && pair_polys()) ? "k_ntt15_p2<true, 2, 0>" : "k_ntt15_p2<true, 1, 0>", 2.0 * X * n * 262144.0);
+        ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * n * 262144.0);
         if (X % 2 == 0 && pair_polys())
             hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
         else

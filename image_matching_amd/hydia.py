@@ -134,6 +134,7 @@ def load_library():
         "hydia_level_reduce": (i32, [vp, vp, u32]),
         "hydia_kernel_time": (i32, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(u64)]),
         "hydia_kernel_time_reset": (i32, [vp]),
+        "hydia_byte_ledger": (i32, [i32, C.c_char_p, sz, C.POINTER(sz)]),
         "hydia_bench_ntt": (i32, [vp, u32, u32, u32, i32, u32, C.POINTER(dbl)]),
     }
     for name, (res, args) in sig.items():
@@ -164,6 +165,19 @@ def _seed(x):
     else:
         b = int(x).to_bytes(32, "little")
     return np.frombuffer(b, dtype=np.uint8).copy()
+
+
+def byte_ledger(enable=-1):
+    """Read the process-wide byte ledger {kernel: (launches, bytes)}, then apply `enable` (1 restart, 0 stop, -1 keep)."""
+    L = load_library()
+    buf = C.create_string_buffer(1 << 16)
+    need = C.c_size_t()
+    _chk(L.hydia_byte_ledger(enable, buf, len(buf), C.byref(need)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, n, b = line.split("\t")
+        out[k] = (int(n), float(b))
+    return out
 
 
 def default_params(**over):

@@ -233,6 +233,11 @@ int hydia_level_reduce(hydia_ctx *ctx, hydia_ct *ct, uint32_t n_limbs);
  * ("hydia_tensor" = loop B's tensor-accumulate kernel, "ks_inner_product") ---- */
 int hydia_kernel_time(hydia_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
 int hydia_kernel_time_reset(hydia_ctx *ctx);
+/* Byte ledger (process-wide): while enabled every kernel launcher records the bytes its launch has to move, by kernel name.
+ * The current table ("kernel<TAB>launches<TAB>bytes" lines) is written to out (NUL-terminated, at most cap bytes; needed = full
+ * size), THEN enable is applied: 1 = clear and record, 0 = stop and clear, -1 = leave as is.  tools/kernel_rooflines.py divides
+ * by the rocprofv3 kernel times of the same run. */
+int hydia_byte_ledger(int enable, char *out, size_t cap, size_t *needed);
 /* NTT microbenchmark on pooled scratch memory: `polys` polynomials x moduli [first_mod, first_mod + n_mods), in place,
  * HIP-event milliseconds per iteration (tools/bench_ntt.py; 512 KiB algorithmic per limb-transform) */
 int hydia_bench_ntt(hydia_ctx *ctx, uint32_t polys, uint32_t first_mod, uint32_t n_mods, int inverse, uint32_t iters,

@@ -1,52 +1,58 @@
 #!/usr/bin/env python3
-"""Copy the outputs of tools/gpu_deliver.sh from gpurun_out/ into profiles/r01/ under a version tag and refresh
-profiles/tensor_traffic.json from the two PMC passes.  Usage: collect_profiles.py v5"""
+"""Copy the outputs of tools/gpu_r2_deliver.sh from gpurun_out/ into profiles/r02/ under a version tag and refresh
+profiles/tensor_traffic.json from the two PMC passes (tagged with the kernel source hash bench.py checks).
+Usage: collect_profiles.py v1"""
 import csv
-import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", "r01")
+G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", "r02")
+os.makedirs(P, exist_ok=True)
+sys.path.insert(0, R)
+from bench import kernel_sha  # noqa: E402
 
 
-def biggest(pattern, needle):
-    """the kernel_stats file of the process that actually ran the workload (the one mentioning the loop-B kernel)"""
-    best = None
-    for f in glob.glob(pattern):
-        txt = open(f).read()
-        if needle in txt and (best is None or len(txt) > len(open(best).read())):
-            best = f
-    return best
+def cp(src, dst):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+    else:
+        print("missing", src)
 
 
-shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, "bench_2p20_%s.json" % tag))
+cp("bench_final.json", "bench_2p20_%s.json" % tag)
 for l in (10, 14, 17):
-    shutil.copy(os.path.join(G, "bench_2p%d.json" % l), os.path.join(P, "bench_2p%d_%s.json" % (l, tag)))
-shutil.copy(biggest(os.path.join(G, "prof_bench_stats2", "*", "*kernel_stats.csv"), "k_hydia_tensor"),
-            os.path.join(P, "bench_2p20_kernel_stats_%s.csv" % tag))
-shutil.copy(biggest(os.path.join(G, "prof_q20c", "*", "*kernel_stats.csv"), "k_hydia_tensor"),
-            os.path.join(P, "indexscenario_2p20_queryonly_kernel_stats_%s.csv" % tag))
-shutil.copy(os.path.join(G, "pmc2_fetch_tensor.csv"), os.path.join(P, "bench_2p20_pmc_fetch_tensor_%s.csv" % tag))
-shutil.copy(os.path.join(G, "pmc2_write_tensor.csv"), os.path.join(P, "bench_2p20_pmc_write_tensor_%s.csv" % tag))
-shutil.copy(os.path.join(G, "cli_2_10.log"), os.path.join(P, "cli_ImageMatching_2_10.log"))
-shutil.copy(os.path.join(G, "latency.csv"), os.path.join(P, "cli_latency.csv"))
+    cp("bench_2p%d.json" % l, "bench_2p%d_%s.json" % (l, tag))
+cp("bench_kernel_stats.csv", "bench_2p20_kernel_stats_%s.csv" % tag)
+for l in (20, 14, 10):
+    cp("kernel_rooflines_q%d.txt" % l, "kernel_rooflines_q%d_%s.txt" % (l, tag))
+    cp("kernel_stats_q%d.csv" % l, "indexscenario_2p%d_queryonly_kernel_stats_%s.csv" % (l, tag))
+    cp("ledger_q%d.json" % l, "byte_ledger_q%d_%s.json" % (l, tag))
+cp("pmc_fetch_tensor.csv", "bench_2p20_pmc_fetch_tensor_%s.csv" % tag)
+cp("pmc_write_tensor.csv", "bench_2p20_pmc_write_tensor_%s.csv" % tag)
+cp("cli_2_10.log", "cli_ImageMatching_2_10.log")
+cp("cli_2_10_sharded.log", "cli_ImageMatching_2_10_three_shards.log")
+cp("latency.csv", "cli_latency.csv")
+cp("pytest_gpu_final.log", "pytest_gpu_%s.log" % tag)
+cp("bench_forcedist.json", "bench_one_rank_rccl_%s.json" % tag)
+cp("bench_rehearse2.json", "bench_two_ranks_gloo_one_gpu_%s.json" % tag)
 
 
 def per_pass(path):
     """sum of the counter over the two loop-B launches (limb 0 + limbs 1-11) of one pass, averaged over passes"""
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["Counter_Value"]) for r in rows)
-    launches = len(rows)
-    return tot / (launches / 2), launches
+    return tot / (len(rows) / 2), len(rows)
 
 
-fetch_kb, nf = per_pass(os.path.join(G, "pmc2_fetch_tensor.csv"))
-write_kb, nw = per_pass(os.path.join(G, "pmc2_write_tensor.csv"))
+fetch_kb, nf = per_pass(os.path.join(G, "pmc_fetch_tensor.csv"))
+write_kb, nw = per_pass(os.path.join(G, "pmc_write_tensor.csv"))
 bench = json.load(open(os.path.join(G, "bench_final.json")))
+head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=R, capture_output=True, text=True).stdout.strip()
 out = {
     "log2n": 20,
     "kernel": "k_hydia_tensor<2,4,nt> (limb 0: 8-byte residues) + k_hydia_tensor<2,4,nt,packed> (limbs 1-11: 6-byte residues)",
@@ -54,8 +60,8 @@ out = {
     "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads; MI355X_MICROARCH.md HBM section)",
     "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (%s)" % tag,
+    "kernel_sha": kernel_sha(), "commit": head,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (r02 %s)" % tag,
 }
 json.dump(out, open(os.path.join(R, "profiles", "tensor_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
-print("bench:", bench["value"], bench["ms_per_step"], bench["roofline"]["achieved"], bench["roofline"]["frac"], bench["cpu_baseline"]["value"])
