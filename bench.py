@@ -321,12 +321,19 @@ def main():
 
 
 def kernel_sha():
-    """identifies the loop-B kernel the committed PMC traffic figure belongs to"""
+    """identifies the loop-B kernel the committed PMC traffic figure belongs to: hash of the source text of k_hydia_tensor (from its
+    template line to the end of its body) and of the packed-residue loader it streams the database with"""
     import hashlib
     h = hashlib.sha256()
-    text = open(os.path.join(ROOT, "image_matching_amd", "csrc", "kernels.hip")).read()
-    i = text.find("k_hydia_tensor")
-    h.update(text[max(0, i - 4000):i + 6000].encode())
+    src = os.path.join(ROOT, "image_matching_amd", "csrc")
+    text = open(os.path.join(src, "kernels.hip")).read()
+    a = text.find("template <int BPP, int NW, bool NT, bool PK>")
+    b = text.find("\n}\n", a)
+    h.update(text[a:b].encode())
+    hdr = open(os.path.join(src, "kernels.h")).read()
+    a = hdr.find("DEV ulonglong2 db_load2")
+    b = hdr.find("\n}\n", a)
+    h.update(hdr[a:b].encode())
     return h.hexdigest()[:16]
 
 

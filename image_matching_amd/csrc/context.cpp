@@ -350,6 +350,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     merge_rescale = getenv("HYDIA_NO_MERGE_RESCALE") == nullptr;
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
+    fuse_loop_a = getenv("HYDIA_NO_FUSE_LOOPA") == nullptr;
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)

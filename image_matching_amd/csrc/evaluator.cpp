@@ -104,23 +104,59 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
                        const unsigned *d_galois, const unsigned *d_ginv, int same_galois, bool dbl, u64 *out, int keys_packed_nQ) {
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const LimbSel esel = sel_ext(nl);
-    u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
-    timer_begin("ks_inner_product");
-    hk::inner_product(stream, d_mod, N, dig, dig_x_stride, nd, d_keys, same_key, nT, acc, X, esel, nullptr, 0, 1, 0, 0, keys_packed_nQ);
-    timer_end("ks_inner_product");
-    // P limbs -> coefficient form, pre-multiplied by (P/p_k)^{-1}
-    LimbSel psel = sel_range(nQ, nT);
-    u64 *y = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
-    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
+    const LimbSel qsel = sel_q(nl);
+    const LimbSel psel = sel_range(nQ, nT);
+    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
     ConvTab tab{};
     tab.ns = nP;
     tab.nt = nl;
     tab.skip_lo = tab.skip_hi = 0;
     for (int k = 0; k < nP; k++)
         for (int j = 0; j < nl; j++) tab.f[k][j] = Phat_mod_q[k][j];
+    // Loop A (one ModUp shared by all X rotations, one key per rotation): the Q limbs of <digits, key> are formed inside the ModDown
+    // transform's epilogue (NttStore mode 5), so only the special-prime limbs of the accumulator ever exist in HBM — the
+    // [X][2][nl][N] part (3 of 4 GiB at X = 511) is neither written nor read back
+    if (prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !fuse_bconv && !dbl) {
+        u64 *accp = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
+        timer_begin("ks_inner_product");
+        hk::inner_product(stream, d_mod, N, dig, 0, nd, d_keys, 0, nT, accp, X, psel, nullptr, 0, 1, 0, nP, keys_packed_nQ, nE, nl);
+        timer_end("ks_inner_product");
+        u64 *y = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
+        ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
+        pool.put(accp);
+        u64 *conv = pool.get((size_t)X * 2 * nl * N * sizeof(u64));
+        hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
+        pool.put(y);
+        NttLoad ld{};
+        NttStore stp{};
+        stp.mode = 5;
+        stp.out = out;
+        stp.nl = nl;
+        stp.mul = scale_of(qsel, pinv, false);
+        stp.addend = addend;
+        stp.add_x = add_x_stride;
+        stp.add_p = add_poly_stride;
+        stp.add_polys = add_polys;
+        stp.ginv = d_ginv;
+        stp.same_g = same_galois;
+        stp.la.keys = d_keys;
+        stp.la.dig = dig;
+        stp.la.nd = nd;
+        stp.la.dig_rows = nE;
+        stp.la.nT = nT;
+        stp.la.packed_nQ = keys_packed_nQ;
+        hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, X * 2, qsel, ld, stp);
+        pool.put(conv);
+        return;
+    }
+    u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
+    timer_begin("ks_inner_product");
+    hk::inner_product(stream, d_mod, N, dig, dig_x_stride, nd, d_keys, same_key, nT, acc, X, esel, nullptr, 0, 1, 0, 0, keys_packed_nQ);
+    timer_end("ks_inner_product");
+    // P limbs -> coefficient form, pre-multiplied by (P/p_k)^{-1}
+    u64 *y = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
+    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
     u64 *conv = pool.get((size_t)X * 2 * nl * N * sizeof(u64));
-    const LimbSel qsel = sel_q(nl);
-    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
     if (prm.logN == 15) {
         // ModDown combine (+ addend, doubling, automorphism scatter) fused into the NTT's second pass; the P -> Q base
         // conversion runs as its own all-targets kernel unless HYDIA_FUSE_BCONV asks for the first-pass fusion

@@ -187,6 +187,7 @@ struct Context : HostParams {
     void ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc);
     // ModUp: c [X][nl][N] at stride c_outer -> dig [X][nd][nE][N]
     void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true, bool p1_only = false);
+    bool fuse_loop_a = true;    // loop A: Q-limb inner product inside the ModDown transform's epilogue (HYDIA_NO_FUSE_LOOPA)
     bool fork_products = true;  // comparator: independent products of a one-block query on two lanes (HYDIA_NO_FORK)
     bool fuse_ip = true;  // relinearisation: second NTT pass of ModUp fused with the inner product (HYDIA_NO_FUSE_IP)
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]

@@ -76,8 +76,15 @@ struct IpArgs {
     size_t c2_xs;
     u64 *acc;         // [x][2][nE][N]
 };
+// store mode 5 = mode 1 whose `in` operand (the key-switching accumulator of the Q limbs) is never materialised: the epilogue forms
+// sum_d dig[d][j][c] * key_x[d][p][j][c] itself from the shared digits (L2-resident) and rotation x's key (loop A)
+struct LoopAIp {
+    const u64 *const *keys;  // device array: key of rotation x (packed when packed_nQ > 0, else [nd][2][nT][N] u64)
+    const u64 *dig;          // [nd][dig_rows][N], shared by every x
+    int nd, dig_rows, nT, packed_nQ;
+};
 struct NttStore {
-    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale, 4 inner product
+    int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale, 4 inner product, 5 see LoopAIp
     u64 *out;             // modes 1,2: destination, compact [xp][nl][N]
     int nl;               // limbs of `out`
     const u64 *in;        // mode 1: acc [xp][in_ls][N] (Q limbs first); mode 2: ciphertext being rescaled [xp][in_ls][N]
@@ -97,6 +104,7 @@ struct NttStore {
     int npoly;
     u64 addc[HY_LC_LIMBS];
     IpArgs ip;            // mode 4
+    LoopAIp la;           // mode 5
 };
 
 
@@ -106,6 +114,34 @@ struct DbLayout {
     unsigned long long ct_bytes, poly_bytes;
     int packed;
 };
+
+// ---- device helpers shared by kernels.hip and ntt15.hip: 48-bit packed residues (database, rotation keys of loop A)
+#if defined(__HIPCC__)
+template <bool PK, bool NT>
+DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
+    if (!PK) {
+        const ull2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(p)) : *reinterpret_cast<const ull2 *>(p);
+        ulonglong2 r;
+        r.x = v.x;
+        r.y = v.y;
+        return r;
+    }
+    const u3 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(p)) : *reinterpret_cast<const u3 *>(p);
+    ulonglong2 r;
+    r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
+    r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
+    return r;
+}
+
+// packed key layout (loop A's rotation keys): per (digit, poly) one row set — modulus 0 as N 8-byte residues, the nQ-1 scaling
+// moduli (< 2^48) as N 6-byte residues each, then the nP special moduli as N 8-byte residues.  -17 % of the 12 GiB key stream.
+HD size_t key_limb_offset(int N, int nQ, int m) {
+    return m == 0 ? 0 : (m < nQ ? (size_t)N * 8 + (size_t)(m - 1) * N * 6 : (size_t)N * 8 + (size_t)(nQ - 1) * N * 6 + (size_t)(m - nQ) * N * 8);
+}
+HD size_t key_set_bytes(int N, int nQ, int nT) { return key_limb_offset(N, nQ, nT); }
+#endif
 
 namespace hk {
 // ---- byte ledger (measurement): when enabled, every launcher below records the bytes its launch has to move (operands read +
@@ -168,7 +204,8 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
 // (same_key: every x uses keys[0])
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dig_x_stride, int nd,
                    const u64 *const *keys, int same_key, int nT, u64 *acc, int X, const LimbSel &esel,
-                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0, int acc_rows = 0, int packed_nQ = 0);
+                   const u64 *own = nullptr, size_t own_x_stride = 0, int alpha = 1, int nl = 0, int acc_rows = 0, int packed_nQ = 0,
+                   int dig_rows = 0 /* rows per digit in dig; default acc_rows */, int dig_t0 = 0 /* digit row of acc row 0 */);
 // packed evaluation keys (loop A): 45/46-bit limbs as 6-byte residues; packed_nQ > 0 tells inner_product that keys[] are packed
 size_t key_packed_bytes(int N, int nQ, int nT, int nd);
 void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out);

@@ -311,37 +311,15 @@ __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ m
     }
 }
 // two consecutive residues of an 8-byte (PK = false) or 6-byte (PK = true) row; NT: non-temporal load
-template <bool PK, bool NT>
-DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
-    if (!PK) {
-        const ull2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(p)) : *reinterpret_cast<const ull2 *>(p);
-        ulonglong2 r;
-        r.x = v.x;
-        r.y = v.y;
-        return r;
-    }
-    const u3 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(p)) : *reinterpret_cast<const u3 *>(p);
-    ulonglong2 r;
-    r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
-    r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
-    return r;
-}
-
-// packed key layout (loop A's rotation keys): per (digit, poly) one row set — modulus 0 as N 8-byte residues, the nQ-1 scaling
-// moduli (< 2^48) as N 6-byte residues each, then the nP special moduli as N 8-byte residues.  -17 % of the 12 GiB key stream.
-HD size_t key_limb_offset(int N, int nQ, int m) {
-    return m == 0 ? 0 : (m < nQ ? (size_t)N * 8 + (size_t)(m - 1) * N * 6 : (size_t)N * 8 + (size_t)(nQ - 1) * N * 6 + (size_t)(m - nQ) * N * 8);
-}
-HD size_t key_set_bytes(int N, int nQ, int nT) { return key_limb_offset(N, nQ, nT); }
 // grid (N/512, nE, X); 2 coefficients per thread, both key polys.  PK: keys[x] points at a packed key (see above)
 template <bool PK>
 __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ mod, int N, const u64 *__restrict__ dig,
                                                        size_t dxs, int nd, const u64 *const *__restrict__ keys,
                                                        int same_key, int nT, u64 *__restrict__ acc, LimbSel esel,
                                                        const u64 *__restrict__ own, size_t own_xs, int alpha, int nl, int acc_rows,
-                                                       int nQ) {
+                                                       int nQ, int dig_rows, int dig_t0) {
+    // acc row t <-> modulus esel.mod[t] <-> digit row dig_t0 + t (dig_t0 > 0: only the special-prime limbs are accumulated here,
+    // the Q limbs' inner product lives in the ModDown transform's epilogue — NttStore mode 5)
     const int t = blockIdx.y, x = blockIdx.z, nE = acc_rows, m = esel.mod[t];
     const ModC M = mod[m];
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
@@ -353,7 +331,7 @@ __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ 
     for (int d = 0; d < nd; d++) {
         // a digit's own limbs are the input itself (evaluation form): read them in place when the caller did not copy them
         const u64 *src = (own && t < nl && t / alpha == d) ? own + (size_t)x * own_xs + (size_t)t * N + c
-                                                           : dig + (size_t)x * dxs + ((size_t)d * nE + t) * N + c;
+                                                           : dig + (size_t)x * dxs + ((size_t)d * dig_rows + dig_t0 + t) * N + c;
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
         ulonglong2 kb, ka;
         if (PK) {
@@ -808,19 +786,22 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
                    int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl,
-                   int acc_rows, int packed_nQ) {
+                   int acc_rows, int packed_nQ, int dig_rows, int dig_t0) {
+    const int rows = acc_rows > 0 ? acc_rows : esel.n, drows = dig_rows > 0 ? dig_rows : rows;
     {   // keys of X rotations streamed once (one shared key: once in all), digits / own limbs once per x unless shared (dxs == 0), acc out
-        const double keyb = packed_nQ > 0 ? (double)key_packed_bytes(N, packed_nQ, nT, nd) * esel.n / nT : (double)nd * 2 * esel.n * LP_BYTES(N);
+        double rowb = 0;  // bytes of one (digit, poly) key row set restricted to the limbs of esel
+        for (int t = 0; t < esel.n; t++) rowb += (packed_nQ > 0 && esel.mod[t] > 0 && esel.mod[t] < packed_nQ) ? N * 6.0 : N * 8.0;
+        const double keyb = nd * 2 * rowb;
         const double digb = (double)nd * esel.n * LP_BYTES(N);
         ledger_add(packed_nQ > 0 ? "k_inner_product<true>" : "k_inner_product<false>",
                    (same_key ? keyb : keyb * X) + (dxs ? digb * X : digb) + 2.0 * X * esel.n * LP_BYTES(N));
     }
     if (packed_nQ > 0)
         hipLaunchKernelGGL(k_inner_product<true>, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
-                           nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n, packed_nQ);
+                           nT, acc, esel, own, own_xs, alpha, nl, rows, packed_nQ, drows, dig_t0);
     else
         hipLaunchKernelGGL(k_inner_product<false>, dim3(N / 512, esel.n, X), dim3(256), 0, st, mod, N, dig, dxs, nd, keys, same_key,
-                           nT, acc, esel, own, own_xs, alpha, nl, acc_rows > 0 ? acc_rows : esel.n, 0);
+                           nT, acc, esel, own, own_xs, alpha, nl, rows, 0, drows, dig_t0);
 }
 size_t key_packed_bytes(int N, int nQ, int nT, int nd) { return (size_t)nd * 2 * key_set_bytes(N, nQ, nT); }
 void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out) {

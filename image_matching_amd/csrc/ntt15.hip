@@ -259,18 +259,51 @@ struct P2Pre {
     ulonglong2 sb0, sb1;            // subtrahend of mode 3
     bool has_ex, has_sb;
 };
+// mode 5: the accumulator value of 4 consecutive coefficients of limb j, key polynomial p, rotation x — formed here instead of
+// being read back: nd lazy 128-bit products per coefficient, one reduction
+DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    constexpr int N = 32768;
+    const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
+    const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
+    const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
+    const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
+    u128 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int d = 0; d < la.nd; d++) {
+        const u64 *dg = la.dig + ((size_t)d * la.dig_rows + j) * N + idx;
+        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(dg), v1 = *reinterpret_cast<const ulonglong2 *>(dg + 2);
+        const unsigned char *kd = kp + (size_t)(2 * d) * set_bytes;
+        ulonglong2 k0, k1;
+        if (six) {
+            k0 = db_load2<true, false>(kd);
+            k1 = db_load2<true, false>(kd + 12);
+        } else {
+            k0 = db_load2<false, false>(kd);
+            k1 = db_load2<false, false>(kd + 16);
+        }
+        a0 += (u128)v0.x * k0.x;
+        a1 += (u128)v0.y * k0.y;
+        a2 += (u128)v1.x * k1.x;
+        a3 += (u128)v1.y * k1.y;
+    }
+    o0 = make_ulonglong2(reduce_lazy(a0, M, la.nd), reduce_lazy(a1, M, la.nd));
+    o1 = make_ulonglong2(reduce_lazy(a2, M, la.nd), reduce_lazy(a3, M, la.nd));
+}
 template <int ST>
-DEV P2Pre p2_prefetch(const NttStore &st, int xp, int j, unsigned idx) {
+DEV P2Pre p2_prefetch(const NttStore &st, int xp, int j, unsigned idx, const ModC &M) {
     constexpr size_t N = 32768;
     P2Pre r;
     r.has_ex = false;
     r.ex0 = r.ex1 = make_ulonglong2(0, 0);
-    const u64 *pi = st.in + ((size_t)xp * st.in_ls + j) * N + idx;
-    r.in0 = *reinterpret_cast<const ulonglong2 *>(pi);
-    r.in1 = *reinterpret_cast<const ulonglong2 *>(pi + 2);
+    if (ST == 5) {
+        loop_a_inner_product(st.la, M, xp >> 1, xp & 1, j, idx, r.in0, r.in1);
+    } else {
+        const u64 *pi = st.in + ((size_t)xp * st.in_ls + j) * N + idx;
+        r.in0 = *reinterpret_cast<const ulonglong2 *>(pi);
+        r.in1 = *reinterpret_cast<const ulonglong2 *>(pi + 2);
+    }
     r.sb0 = r.sb1 = make_ulonglong2(0, 0);
     r.has_sb = false;
-    if (ST == 1 || ST == 3) {
+    if (ST == 1 || ST == 3 || ST == 5) {
         const int x = xp >> 1, p = xp & 1;
         if (st.addend && p < st.add_polys) {
             const u64 *pa = st.addend + (size_t)x * st.add_x + (size_t)p * st.add_p + (size_t)j * N + idx;
@@ -322,7 +355,7 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         r[k] = mulmod_shoup(submod(iv[k], v[k], q), mul, muls, q);
-        if (ST == 1) {
+        if (ST == 1 || ST == 5) {
             if (pre.has_ex) r[k] = addmod(r[k], ev[k], q);
             if (st.dbl) r[k] = addmod(r[k], r[k], q);
         } else {
@@ -332,7 +365,7 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     }
     u64 *o = st.out + ((size_t)xp * st.nl + j) * N;
     unsigned g = 1u;
-    if (ST == 1 && st.ginv) g = st.ginv[st.same_g ? 0 : (xp >> 1)];
+    if ((ST == 1 || ST == 5) && st.ginv) g = st.ginv[st.same_g ? 0 : (xp >> 1)];
     if (g != 1u) {
 #pragma unroll
         for (int k = 0; k < 4; k++) o[perm_idx(idx + k, g)] = r[k];
@@ -411,7 +444,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
             for (int hh = 0; hh < 2; hh++)
 #pragma unroll
-                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh));
+                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh), M);
         }
         __syncthreads();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
@@ -772,12 +805,12 @@ __global__ __launch_bounds__(1024) void k_ntt15_1p(NttTables T, const ulonglong2
                     W14b[f] = w14.y;
                 }
                 P2Pre pre = {};
-                if (ST != 0) pre = p2_prefetch<ST>(stp, xp, slot, (unsigned)((4 * h) * 4096 + 4 * t));
+                if (ST != 0) pre = p2_prefetch<ST>(stp, xp, slot, (unsigned)((4 * h) * 4096 + 4 * t), M);
 #pragma unroll
                 for (int f = 0; f < 4; f++) {
                     const int gi = (4 * h + f) * 1024 + t;
                     P2Pre nxt = {};
-                    if (ST != 0 && f < 3) nxt = p2_prefetch<ST>(stp, xp, slot, (unsigned)(4 * (gi + 1024)));
+                    if (ST != 0 && f < 3) nxt = p2_prefetch<ST>(stp, xp, slot, (unsigned)(4 * (gi + 1024)), M);
                     // one group at a time out of LDS: the other half's 32 values are still waiting in registers
                     double c0 = FpA::from_bits(lds[f * 128 * 33 + rd]), c1 = FpA::from_bits(lds[f * 128 * 33 + rd + 1]),
                            c2 = FpA::from_bits(lds[f * 128 * 33 + rd + 2]), c3 = FpA::from_bits(lds[f * 128 * 33 + rd + 3]);
@@ -995,7 +1028,10 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
     {   // pass-1 output in, result out, + the epilogue's operands: acc & addend (1), rescale input (2), both + subtrahend (3)
         char name[64];
         snprintf(name, sizeof name, "k_ntt15_p2<false, %d, %d>", (X % 2 == 0 && pair_polys()) ? 2 : 1, ST);
-        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * X * nsl * 262144.0);
+        double per = (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * 262144.0;
+        if (ST == 5)  // pass-1 output in, result out, addend on every other polynomial, nd key rows (6- or 8-byte residues); digits from L2
+            per = 2.5 * 262144.0 + stp.la.nd * 32768.0 * (stp.la.packed_nQ > 0 ? (6.0 * (nsl - 1) + 8.0) / nsl : 8.0);
+        ledger_add(name, per * X * nsl);
     }
     if (X % 2 == 0 && pair_polys())
         hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
@@ -1045,6 +1081,7 @@ void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64
         return;
     }
     if (stp.mode == 1) forward_runs<0, 1>(st, T, src, dst, so, dso, X, sel, ld, stp);
+    else if (stp.mode == 5) forward_runs<0, 5>(st, T, src, dst, so, dso, X, sel, ld, stp);
     else if (stp.mode == 2) forward_runs<0, 2>(st, T, src, dst, so, dso, X, sel, ld, stp);
     else if (stp.mode == 3) forward_runs<0, 3>(st, T, src, dst, so, dso, X, sel, ld, stp);
     else forward_runs<0, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);

@@ -282,7 +282,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     variants = [
         {},
         {"HYDIA_NTT_INT": "1", "HYDIA_DB_UNPACKED": "1", "HYDIA_KEYS_UNPACKED": "1", "HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1",
-         "HYDIA_LANES": "1", "HYDIA_NO_FORK": "1"},
+         "HYDIA_LANES": "1", "HYDIA_NO_FORK": "1", "HYDIA_NO_FUSE_LOOPA": "1"},
         {"HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "3"},
         {"HYDIA_NTT_1PASS": "1", "HYDIA_NTT_1PASS_MIN": "1"},  # the one-pass kernel (one HBM round trip) for every FP64 limb transform
         {"HYDIA_NTT_1PASS": "1"},  # ... only for launches of at least 1024 limb-polynomials
@@ -295,7 +295,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     results = []
     for env in variants:
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
-                  "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK"):
+                  "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

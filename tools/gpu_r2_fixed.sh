@@ -1,10 +1,10 @@
 # fixed-cost regime work: parity of everything, then A/B at 2^10 / 2^14 / 2^20
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_fixed.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu_fixed.log; tail -6 gpurun_out/pytest_gpu_fixed.log
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_ring.py -m gpu -q -x > gpurun_out/pytest_gpu_fixed.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu_fixed.log; tail -6 gpurun_out/pytest_gpu_fixed.log
 grep -q "pytest exit 0" gpurun_out/pytest_gpu_fixed.log || exit 1
 for L in 10 14 20; do
-  for cfg in "HYDIA_NO_FORK=1" "X=1"; do
+  for cfg in "HYDIA_NO_FUSE_LOOPA=1" "X=1"; do
     env $cfg timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --log2n $L > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -3 gpurun_out/ab.err; exit 1; }
     python -c "
 import json; d=json.load(open('gpurun_out/ab.json')); print('2^$L', '$cfg', round(d['ms_per_step'],2), 'ms/step  similarity', d['config']['secondary']['computeSimilarity_ms_per_query'], d['config']['result_correct'])"
