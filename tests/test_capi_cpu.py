@@ -81,3 +81,26 @@ def test_product_never_touches_the_oracle():
     import subprocess
     ldd = subprocess.run(["ldd", os.path.join(pkg, "libhydia.so")], capture_output=True, text=True).stdout
     assert "oracle" not in ldd
+
+
+def test_cli_usage_errors_and_roles_header_compile(tmp_path):
+    """./ImageMatching keeps the reference driver's argument contract (src/main.cpp:46-70) — checked before any GPU work, so it
+    runs on a CPU-only box — and include/hydia_roles.hpp compiles on its own against include/hydia.h (plain g++, no HIP)."""
+    import subprocess
+    exe = os.path.join(ROOT, "image_matching_amd", "ImageMatching")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    (tmp_path / "latency.csv").write_text("")
+    dat = tmp_path / "tiny.dat"
+    dat.write_text("1\n" + " ".join(["1"] * 512) + "\n" + " ".join(["2"] * 512) + "\n")
+    cases = [([], "input file not included"), ([str(tmp_path / "missing.dat")], "unable to open input file"),
+             ([str(dat)], "approach argument not included"), ([str(dat), "7"], "approach must be from 1 to 5"),
+             ([str(dat), "2"], "only approach 5")]
+    for args, msg in cases:
+        out = subprocess.run([exe] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+        assert out.returncode != 0 and msg in out.stderr, (args, out.stderr)
+        assert "Running Setup Operations" in out.stdout
+    src = tmp_path / "roles_only.cpp"
+    src.write_text('#include "hydia_roles.hpp"\nint main() { hydia::Sender *s = nullptr; (void)s; return hydia::OpenFHEWrapper::computeRequiredDepth(5) == 11 ? 0 : 1; }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
