@@ -351,6 +351,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
     fuse_loop_a = getenv("HYDIA_NO_FUSE_LOOPA") == nullptr;
+    if (const char *e = getenv("HYDIA_SLICE_MIB")) slice_bytes = (size_t)atol(e) << 20;
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)

@@ -117,36 +117,39 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     // transform's epilogue (NttStore mode 5), so only the special-prime limbs of the accumulator ever exist in HBM — the
     // [X][2][nl][N] part (3 of 4 GiB at X = 511) is neither written nor read back
     if (prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !fuse_bconv && !dbl) {
-        u64 *accp = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
-        timer_begin("ks_inner_product");
-        hk::inner_product(stream, d_mod, N, dig, 0, nd, d_keys, 0, nT, accp, X, psel, nullptr, 0, 1, 0, nP, keys_packed_nQ, nE, nl);
-        timer_end("ks_inner_product");
-        u64 *y = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
-        ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
-        pool.put(accp);
-        u64 *conv = pool.get((size_t)X * 2 * nl * N * sizeof(u64));
-        hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
-        pool.put(y);
-        NttLoad ld{};
-        NttStore stp{};
-        stp.mode = 5;
-        stp.out = out;
-        stp.nl = nl;
-        stp.mul = scale_of(qsel, pinv, false);
-        stp.addend = addend;
-        stp.add_x = add_x_stride;
-        stp.add_p = add_poly_stride;
-        stp.add_polys = add_polys;
-        stp.ginv = d_ginv;
-        stp.same_g = same_galois;
-        stp.la.keys = d_keys;
-        stp.la.dig = dig;
-        stp.la.nd = nd;
-        stp.la.dig_rows = nE;
-        stp.la.nT = nT;
-        stp.la.packed_nQ = keys_packed_nQ;
-        hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, X * 2, qsel, ld, stp);
-        pool.put(conv);
+        {
+            const int x0 = 0, Xc = X;
+            u64 *accp = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
+            timer_begin("ks_inner_product");
+            hk::inner_product(stream, d_mod, N, dig, 0, nd, d_keys + x0, 0, nT, accp, Xc, psel, nullptr, 0, 1, 0, nP, keys_packed_nQ, nE, nl);
+            timer_end("ks_inner_product");
+            u64 *y = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
+            ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true));
+            pool.put(accp);
+            u64 *conv = pool.get((size_t)Xc * 2 * nl * N * sizeof(u64));
+            hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, Xc * 2, tab, qsel);
+            pool.put(y);
+            NttLoad ld{};
+            NttStore stp{};
+            stp.mode = 5;
+            stp.out = out + (size_t)x0 * 2 * nl * N;
+            stp.nl = nl;
+            stp.mul = scale_of(qsel, pinv, false);
+            stp.addend = addend ? addend + (size_t)x0 * add_x_stride : nullptr;
+            stp.add_x = add_x_stride;
+            stp.add_p = add_poly_stride;
+            stp.add_polys = add_polys;
+            stp.ginv = d_ginv ? (same_galois ? d_ginv : d_ginv + x0) : nullptr;
+            stp.same_g = same_galois;
+            stp.la.keys = d_keys + x0;
+            stp.la.dig = dig;
+            stp.la.nd = nd;
+            stp.la.dig_rows = nE;
+            stp.la.nT = nT;
+            stp.la.packed_nQ = keys_packed_nQ;
+            hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
+            pool.put(conv);
+        }
         return;
     }
     u64 *acc = pool.get((size_t)X * 2 * nE * N * sizeof(u64));
@@ -311,6 +314,31 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     }
     if (!relin_key.d) throw StateError("hydia: relinearisation key not loaded");
     if (sub && (sub->X != c.X || sub->npoly != 2 || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
+    // Experiment switch HYDIA_SLICE_MIB (default off): walk the batch in slices whose intermediates (~ (nd + 2)(nl + nP) + 3 nl + 2 l
+    // limb-polynomials per ciphertext) fit the 256 MiB Infinity Cache, so that every producer -> consumer hand-off of a slice finds
+    // its operand in cache.  Measured at 2^20: 66.3 ms unsliced, 76.8 / 110.6 / 206.8 ms at 192 / 96 / 48 MiB — the slices' kernels
+    // last 10-30 us and the query becomes launch-bound (5-20x more launches); kept only so the measurement can be repeated.
+    const int nE0 = nl + nP, nd0 = (nl + alpha - 1) / alpha;
+    const size_t per_ct = ((size_t)(nd0 + 2) * nE0 + 3 * nl + 2 * l) * N * sizeof(u64);
+    const int chunk = slice_bytes ? (int)std::max<size_t>(1, slice_bytes / per_ct) : c.X;
+    Ct out(this, c.X, 2, l, c.scale / (double)q[l]);
+    for (int x0 = 0; x0 < c.X; x0 += chunk) {
+        Ct part = c.alias(c.nl);
+        part.X = std::min(chunk, c.X - x0);
+        part.d = c.d + (size_t)x0 * c.ct_elems();
+        Ct sv;
+        if (sub) {
+            sv = sub->alias(sub->nl);
+            sv.X = part.X;
+            sv.d = sub->d + (size_t)x0 * sub->ct_elems();
+        }
+        relin_rescale_slice(part, dbl, sub ? &sv : nullptr, addc, sub_is_add, out.d + (size_t)x0 * out.ct_elems());
+    }
+    c = std::move(out);
+}
+// one slice of relin_rescale: c [X][3][nl][N] (a view) -> out_d [X][2][nl - 1][N]
+void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d) {
+    const int nl = c.nl, l = nl - 1;
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     const u64 *c2 = c.d + 2 * c.poly_elems();
@@ -352,12 +380,12 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     u64 *w = pool.get((size_t)XP * l * N * sizeof(u64));
     hk::moddown_rescale_conv(stream, d_mod, N, y, u, w, XP, l, nP, tab);
     const LimbSel qsel = sel_q(l);
-    Ct out(this, X, 2, l, c.scale / (double)q[l]);
+    const double out_scale = c.scale / (double)q[l];
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
     NttLoad ld{};
     NttStore stp{};
     stp.mode = 3;
-    stp.out = out.d;
+    stp.out = out_d;
     stp.nl = l;
     stp.in = acc;
     stp.in_ls = nE;
@@ -374,13 +402,12 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     stp.has_addc = addc ? 1 : 0;
     stp.npoly = 2;
     if (addc)
-        for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out.scale, q[j]);
+        for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out_scale, q[j]);
     hk::ntt15_forward_fused(stream, tabs, w, w, (size_t)l * N, (size_t)l * N, XP, qsel, ld, stp);
     pool.put(w);
     pool.put(u);
     pool.put(y);
     pool.put(acc);
-    c = std::move(out);
 }
 Ct Context::clone(const Ct &a) {
     Ct o(this, a.X, a.npoly, a.nl, a.scale);

@@ -203,6 +203,8 @@ struct Context : HostParams {
     // the dropped limb of the ModDown output is obtained in the coefficient domain, so ModDown's and Rescale's
     // corrections share a single forward NTT per remaining limb ((l+1) transforms per polynomial saved)
     void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
+    void relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d);
+    size_t slice_bytes = 0;  // experiment: working set of one slice of a batched key switch (HYDIA_SLICE_MIB; 0 = whole batch)
     bool merge_rescale = true;      // HYDIA_NO_MERGE_RESCALE: run the two steps separately (A/B)
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
