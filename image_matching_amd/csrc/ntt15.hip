@@ -48,6 +48,7 @@ struct IntA {
         a = s;
     }
     DEV void recentre(T &) const {}
+    DEV void recentre_wide(T &) const {}
     DEV u64 fin_fwd(T x) const {
         x = x >= q2 ? x - q2 : x;
         return x >= q ? x - q : x;
@@ -59,7 +60,8 @@ struct FpA {
     typedef double T;
     typedef double2 TW;  // (w, w / q)
     double q, qinv;
-    DEV FpA(const ModC &M) : q((double)M.q), qinv(1.0 / (double)M.q) {}
+    bool lean;  // q < 2^45 (1 + 1/16), true for every scaling prime of the default chain: 32 q stays below 2^50.1
+    DEV FpA(const ModC &M) : q((double)M.q), qinv(1.0 / (double)M.q), lean(M.q < (1ull << 45) + (1ull << 41)) {}
     DEV static TW tw(const ulonglong2 b) { return make_double2(__longlong_as_double((long long)b.x), __longlong_as_double((long long)b.y)); }
     // twiddle given alone: w / q as w * (1/q).  The quotient estimate of mulmod may then be off by one more in rare cases: the result
     // stays an exact representative of a*w (|r| <= ~1.3 q instead of 0.75 q), which the transforms' headroom (< 2^52) absorbs
@@ -87,6 +89,12 @@ struct FpA {
         a = s;
     }
     DEV void recentre(T &x) const { x = __fma_rn(-rint(x * qinv), q, x); }  // -> [-q/2, q/2]
+    // The inverse transform doubles magnitudes on its sum path; a reduction every 3-4 stages keeps 47-bit primes below 2^52.  For
+    // the lean primes two of the four reductions of the two-pass inverse can go: runs of 5 and 6 stages reach 32 q < 2^50.1, where
+    // products and quotient estimates are still exact enough (|quotient error| <= 1, results exact).  Final residues are unchanged.
+    DEV void recentre_wide(T &x) const {
+        if (!lean) recentre(x);
+    }
     DEV u64 fin_fwd(T x) const {
         recentre(x);
         if (x < 0) x += q;
@@ -521,7 +529,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 ar.gs(c2, c3, W14b);
                 ar.gs(c0, c2, W13);
                 ar.gs(c1, c3, W13);
-                ar.recentre(c0); ar.recentre(c1); ar.recentre(c2); ar.recentre(c3);
+                ar.recentre_wide(c0); ar.recentre_wide(c1); ar.recentre_wide(c2); ar.recentre_wide(c3);
                 lds[p][la] = A::to_bits(c0); lds[p][la + 1] = A::to_bits(c1);
                 lds[p][la + 2] = A::to_bits(c2); lds[p][la + 3] = A::to_bits(c3);
             }
@@ -576,7 +584,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W7);
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    ar.recentre(v[p][k]);
+                    ar.recentre_wide(v[p][k]);
                     d[p][blk * 256 + 32 * k + w] = A::to_bits(v[p][k]);  // raw: pass 1' finishes
                 }
             }
