@@ -1,4 +1,5 @@
-# A/B: slicing batched key switches / loop A so that intermediates stay in the Infinity Cache
+# A/B: slicing batched key switches / loop A so that intermediates stay in the Infinity Cache (result: profiles/r02/slicing_for_infinity_cache_ab.txt;
+# HYDIA_SLICE_A_MIB — loop A — was removed from the library after this run, HYDIA_SLICE_MIB remains as an experiment switch)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for L in 20 14; do
