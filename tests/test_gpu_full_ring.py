@@ -159,3 +159,62 @@ def test_reference_dataset_2_11_bit_exact_full_ring(im, full):
     mem, gmem = Or.membership_scenario(q, dbc, n), sender.membershipScenario(gq)
     assert np.array_equal(gmem.export()[0], mem.data())
     assert receiver.decryptMembership(gmem) is True and bool(g["expected_membership"])
+
+
+def test_hoisted_rotations_bit_exact_full_ring(im, full):
+    """Loop A on its own at N = 2^15 (the fused path: inner product of the special-prime limbs, ModDown transform whose epilogue forms
+    the Q-limb inner product on the fly from the packed keys, automorphism scatter): every one of the 512 rotated query ciphertexts
+    equals the oracle's EvalFastRotation (sender_diag.cpp:20-26)."""
+    P, K, Or, cc = full
+    qv = np.linspace(-1.0, 1.0, 512)
+    q = Or.encrypt_query(qv, 9, 3)
+    gq = im.DiagonalReceiver(cc, 10).encryptQuery(qv, seed=9, nonce=3)
+    assert np.array_equal(gq.export()[0], q.data())
+    rot = Or.rotate_query(q)
+    grot = im.DiagonalSender(cc, 10).rotateQuery(gq).export()
+    assert grot.shape[0] == 512
+    for i in range(512):
+        assert np.array_equal(grot[i], rot[i].data()), i
+    # decrypted: slot s of rotation i holds the (tiled) query coordinate (s + i) mod 512
+    z = cc.decrypt(cc.import_ct(grot[5:6], gq.shape()[3]))[0]
+    qn = qv / np.linalg.norm(qv)
+    assert np.abs(z[:512] - np.roll(qn, -5)).max() < 1e-7
+
+
+def test_no_match_and_hers_bit_exact_full_ring(im, full):
+    """A database without a match (membership `false`, empty index) and approach 4 (HERS) at N = 2^15, ciphertexts equal to the oracle's."""
+    P, K, Or, cc = full
+    rng = np.random.default_rng(5)
+    n = 3000
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
+    query = np.ones(512)
+    a = db.copy()
+    dbc = Or.enroll(a, 4)
+    im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=4)
+    q = Or.encrypt_query(query, 6, 1)
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    gq = receiver.encryptQuery(query, seed=6, nonce=1)
+    mem, gmem = Or.membership_scenario(q, dbc, n), sender.membershipScenario(gq)
+    assert np.array_equal(gmem.export()[0], mem.data())
+    assert receiver.decryptMembership(gmem) is False and receiver.decryptIndex(sender.indexScenario(gq)) == []
+    del dbc
+    # HERS: column packing, 512 query ciphertexts, relinearise + rescale per product (sender_hers.cpp:60-87)
+    n = 1200
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
+    db[77] = rng.integers(1, 4, size=512)
+    a = db.copy()
+    hdb = Or.hers_enroll(a, 4)
+    im.HersEnroller(cc, n).serializeDB(db.copy(), seed=4)
+    assert cc.db_stats()[1] == len(hdb) == 512
+    for t in (0, 300, 511):
+        assert np.array_equal(cc.db_export_ct(t), hdb[t].data()), t
+    hq = Or.hers_encrypt_query(query, 6, 1000)
+    ghq = im.HersReceiver(cc, n).encryptQuery(query, seed=6, nonce=1000)
+    hs = im.HersSender(cc, n)
+    sim, gsim = Or.hers_compute_similarity(hq, hdb, n), hs.computeSimilarity(ghq).export()
+    assert np.array_equal(gsim[0], sim[0].data())
+    idx, gidx = Or.hers_index_scenario(hq, hdb, n), hs.indexScenario(ghq)
+    assert np.array_equal(gidx.export()[0], idx[0].data())
+    assert receiver.decryptIndex(gidx) == [77]
+    hmem, ghmem = Or.hers_membership_scenario(hq, hdb, n), hs.membershipScenario(ghq)
+    assert np.array_equal(ghmem.export()[0], hmem.data()) and receiver.decryptMembership(ghmem) is True
