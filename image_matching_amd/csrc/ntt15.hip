@@ -1003,11 +1003,13 @@ static void for_slot_runs(const NttTables &T, const LimbSel &sel, bool split, F 
 template <bool INV, int LD, int ST>
 static void launch_1p(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel,
                       int slot0, int nsl, const ScaleSel &scale, const NttLoad &ld, const NttStore &stp) {
-    static bool attr_done = false;  // > 64 KiB of dynamic LDS has to be granted per kernel
-    if (!attr_done) {
+    static bool attr_done[64] = {};  // > 64 KiB of dynamic LDS has to be granted per kernel and per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt15_1p<INV, LD, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   OP_LDS_ELEMS * (int)sizeof(u64));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const int nitems = X * nsl;
     {
