@@ -287,3 +287,43 @@ def test_db_save_load_round_trip(im, tmp_path):
     del q, q2
     for c in (cc, c2, c3):
         c.close()
+
+
+def test_shard_group_full_size_2p20(im):
+    """BASELINE config 5's database (2^20 vectors, 64 blocks, 148 GiB resident) through the sharded sender with two shards on the one
+    GPU: index batch (global block order), decrypted global indices and the membership ciphertext equal the single-context run's."""
+    n = 1 << 20
+    planted = [0, 12345, n // 2 + 3, n - 1]
+    rng = np.random.default_rng(2020)
+    db = rng.integers(-99, 100, size=(n, 512), dtype=np.int8).astype(np.float64)
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    query = np.ones(512)
+    prm = im.default_params()
+    cc = im.Context(prm, 0)
+    cc.keygen(31)
+    a = db.copy()
+    im.DiagonalEnroller(cc, n).serializeDB(a, seed=8)
+    del a
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    q = receiver.encryptQuery(query, seed=2, nonce=9)
+    idx = sender.indexScenario(q)
+    assert receiver.decryptIndex(idx) == planted
+    want_idx, want_mem, want_q = idx.export(), sender.membershipScenario(q).export(), q.export()
+    del q, idx
+    cc.close()
+    grp = im.ShardGroup([0, 0], prm)
+    grp.keygen(31)
+    im.ShardedDiagonalEnroller(grp, n).serializeDB(db, seed=8)
+    del db
+    assert grp.shard_range(0) == (0, n // 2) and grp.shard_range(1) == (n // 2, n // 2)
+    gr, gs = im.DiagonalReceiver(grp.ctx0, n), im.ShardedDiagonalSender(grp, n)
+    gq = gr.encryptQuery(query, seed=2, nonce=9)
+    assert np.array_equal(gq.export(), want_q)
+    gidx = gs.indexScenario(gq)
+    assert len(gidx) == 64 and np.array_equal(gidx.export(), want_idx)
+    assert gr.decryptIndex(gidx) == planted
+    gmem = gs.membershipScenario(gq)
+    assert np.array_equal(gmem.export(), want_mem) and gr.decryptMembership(gmem) is True
+    del gq, gidx, gmem
+    grp.close()
