@@ -456,6 +456,7 @@ void Context::adopt_keys(Context &src) {
     d_pk = src.d_pk;
     d_rotpack = src.d_rotpack;
     rotptrs_packed = src.rotptrs_packed;
+    rotptrs_premul = src.rotptrs_premul;
     keys_borrowed = true;
     HIP_CHECK(hipMemcpyAsync((void *)d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)prm.dim, hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(d_rotgalois, src.d_rotgalois, sizeof(unsigned) * (size_t)prm.dim, hipMemcpyDeviceToDevice, stream));

@@ -116,7 +116,13 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     // Loop A (one ModUp shared by all X rotations, one key per rotation): the Q limbs of <digits, key> are formed inside the ModDown
     // transform's epilogue (NttStore mode 5), so only the special-prime limbs of the accumulator ever exist in HBM — the
     // [X][2][nl][N] part (3 of 4 GiB at X = 511) is neither written nor read back
+    const bool premul = keys_packed_nQ > 0 && rotptrs_premul;  // the packed shadow's Q-limb rows already carry P^{-1}
+    if (premul && !(prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !fuse_bconv && !dbl))
+        throw std::runtime_error("hydia: pre-scaled rotation keys outside the fused loop A");
     if (prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !fuse_bconv && !dbl) {
+        if (premul)
+            for (int k = 0; k < nP; k++)
+                for (int j = 0; j < nl; j++) tab.f[k][j] = mulmod_u64(Phat_mod_q[k][j], Pinv_mod_q[j], q[j]);
         {
             const int x0 = 0, Xc = X;
             u64 *accp = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
@@ -147,6 +153,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
             stp.la.dig_rows = nE;
             stp.la.nT = nT;
             stp.la.packed_nQ = keys_packed_nQ;
+            stp.la.premul = premul ? 1 : 0;
             hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
             pool.put(conv);
         }
@@ -218,11 +225,15 @@ void Context::build_rotptrs() {
         d_rotpack = nullptr;  // not enough HBM for the shadow: loop A reads the plain keys
         pack = false;
     }
+    // with the fused loop A the shadow's Q-limb rows carry P^{-1} (see k_key_pack): only that path reads them
+    const bool premul = pack && fuse_loop_a && prm.logN == 15 && !fuse_bconv;
+    std::vector<u64> pinv_all(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nQ);
+    const ScaleSel pinv_sel = scale_of(sel_q(nQ), pinv_all, false);
     for (int i = 1; i < prm.dim; i++) {
         auto it = rot_keys.find(i);
         if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(i) + " not loaded");
         if (pack) {
-            hk::key_pack(stream, N, nQ, nT, prm.dnum, it->second.d, d_rotpack + kb * (size_t)(i - 1));
+            hk::key_pack(stream, d_mod, N, nQ, nT, prm.dnum, it->second.d, d_rotpack + kb * (size_t)(i - 1), premul ? &pinv_sel : nullptr);
             ptrs[i] = reinterpret_cast<const u64 *>(d_rotpack + kb * (size_t)(i - 1));
         } else {
             ptrs[i] = it->second.d;
@@ -233,6 +244,7 @@ void Context::build_rotptrs() {
         ginv[i] = (unsigned)(x & (2ull * N - 1));
     }
     rotptrs_packed = pack;
+    rotptrs_premul = premul;
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipMemcpy(d_rotginv, ginv.data(), sizeof(unsigned) * prm.dim, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy((void *)d_rotptrs, ptrs.data(), sizeof(u64 *) * prm.dim, hipMemcpyHostToDevice));

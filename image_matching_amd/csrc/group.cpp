@@ -223,6 +223,7 @@ int hydia_group_keygen(hydia_group *g, const uint8_t seed[32]) {
             src.build_rotptrs();
             src.sync_all();
             cx.rotptrs_packed = src.rotptrs_packed;
+            cx.rotptrs_premul = src.rotptrs_premul;
             cx.d_rotpack = src.d_rotpack;
             HIP_CHECK(hipMemcpyAsync((void *)cx.d_rotptrs, (const void *)src.d_rotptrs, sizeof(u64 *) * (size_t)cx.prm.dim,
                                      hipMemcpyDeviceToDevice, cx.stream));

@@ -137,7 +137,7 @@ struct Context : HostParams {
     const u64 **d_rotptrs = nullptr;   // device array: key pointers of rotations 1..dim-1 (hoisted loop A)
     unsigned *d_rotgalois = nullptr;   // device array: their Galois elements
     unsigned *d_rotginv = nullptr;     // device array: inverse Galois elements (scatter form of the automorphism)
-    bool rotptrs_valid = false, rotptrs_packed = false;
+    bool rotptrs_valid = false, rotptrs_packed = false, rotptrs_premul = false;
     unsigned char *d_rotpack = nullptr;  // packed shadow of rotation keys 1..dim-1 (45/46-bit limbs as 6-byte residues), loop A only
     bool rot_packed = true;              // HYDIA_KEYS_UNPACKED turns the shadow off
     // Contexts on the SAME GPU (shards of one database that share a device) can use one resident copy of the keys: this

@@ -82,6 +82,7 @@ struct LoopAIp {
     const u64 *const *keys;  // device array: key of rotation x (packed when packed_nQ > 0, else [nd][2][nT][N] u64)
     const u64 *dig;          // [nd][dig_rows][N], shared by every x
     int nd, dig_rows, nT, packed_nQ;
+    int premul;              // keys (Q-limb rows) and the converted rows already carry P^{-1}: the combine is a plain subtraction
 };
 struct NttStore {
     int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale, 4 inner product, 5 see LoopAIp
@@ -208,7 +209,8 @@ void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_
                    int dig_rows = 0 /* rows per digit in dig; default acc_rows */, int dig_t0 = 0 /* digit row of acc row 0 */);
 // packed evaluation keys (loop A): 45/46-bit limbs as 6-byte residues; packed_nQ > 0 tells inner_product that keys[] are packed
 size_t key_packed_bytes(int N, int nQ, int nT, int nd);
-void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out);
+// premul (optional): per-modulus factor applied to the Q-limb rows while packing (P^{-1} mod q_j for the fused loop A)
+void key_pack(hipStream_t st, const ModC *mod, int N, int nQ, int nT, int nd, const u64 *key, void *out, const ScaleSel *premul = nullptr);
 // second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every
 // extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2)
 void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,

@@ -361,10 +361,18 @@ __global__ __launch_bounds__(256) void k_inner_product(const ModC *__restrict__ 
     *reinterpret_cast<ulonglong2 *>(acc + (((size_t)x * 2 + 1) * nE + t) * N + c) = r1;
 }
 // [nd][2][nT][N] u64 -> packed key.  grid (N/512, nT, nd*2)
-__global__ __launch_bounds__(256) void k_key_pack(int N, int nQ, int nT, const u64 *__restrict__ key, unsigned char *__restrict__ out) {
+// premul: the Q-limb rows are stored multiplied by P^{-1} mod q_j (mul.s[j]) — loop A's fused ModDown epilogue then needs no
+// multiplication at all: (acc - conv) P^{-1} = acc' - conv' with both operands pre-scaled (NttStore mode 5, LoopAIp::premul)
+__global__ __launch_bounds__(256) void k_key_pack(const ModC *__restrict__ mod, int N, int nQ, int nT, const u64 *__restrict__ key,
+                                                  unsigned char *__restrict__ out, int premul, ScaleSel mul) {
     const int m = blockIdx.y, dp = blockIdx.z;
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
-    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(key + ((size_t)dp * nT + m) * N + c);
+    ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(key + ((size_t)dp * nT + m) * N + c);
+    if (premul && m < nQ) {
+        const u64 q = mod[m].q;
+        v.x = mulmod_shoup(v.x, mul.s[m], mul.s_sh[m], q);
+        v.y = mulmod_shoup(v.y, mul.s[m], mul.s_sh[m], q);
+    }
     const bool six = m > 0 && m < nQ;
     unsigned char *d = out + (size_t)dp * key_set_bytes(N, nQ, nT) + key_limb_offset(N, nQ, m) + c * (six ? 6 : 8);
     typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
@@ -804,9 +812,10 @@ void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_
                            nT, acc, esel, own, own_xs, alpha, nl, rows, 0, drows, dig_t0);
 }
 size_t key_packed_bytes(int N, int nQ, int nT, int nd) { return (size_t)nd * 2 * key_set_bytes(N, nQ, nT); }
-void key_pack(hipStream_t st, int N, int nQ, int nT, int nd, const u64 *key, void *out) {
+void key_pack(hipStream_t st, const ModC *mod, int N, int nQ, int nT, int nd, const u64 *key, void *out, const ScaleSel *premul) {
     ledger_add("k_key_pack", (double)nd * 2 * nT * LP_BYTES(N) + (double)key_packed_bytes(N, nQ, nT, nd));
-    hipLaunchKernelGGL(k_key_pack, dim3(N / 512, nT, nd * 2), dim3(256), 0, st, N, nQ, nT, key, (unsigned char *)out);
+    hipLaunchKernelGGL(k_key_pack, dim3(N / 512, nT, nd * 2), dim3(256), 0, st, mod, N, nQ, nT, key, (unsigned char *)out, premul ? 1 : 0,
+                       premul ? *premul : ScaleSel{});
 }
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
                      const u64 *addend, size_t axs, size_t aps, int add_polys, u64 *out, int X, int nl,

@@ -362,7 +362,7 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        r[k] = mulmod_shoup(submod(iv[k], v[k], q), mul, muls, q);
+        r[k] = (ST == 5 && st.la.premul) ? submod(iv[k], v[k], q) : mulmod_shoup(submod(iv[k], v[k], q), mul, muls, q);
         if (ST == 1 || ST == 5) {
             if (pre.has_ex) r[k] = addmod(r[k], ev[k], q);
             if (st.dbl) r[k] = addmod(r[k], r[k], q);
