@@ -154,6 +154,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
             stp.la.nT = nT;
             stp.la.packed_nQ = keys_packed_nQ;
             stp.la.premul = premul ? 1 : 0;
+            stp.la.fp = getenv("HYDIA_LOOPA_INT_IP") ? 0 : 1;
             hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
             pool.put(conv);
         }

@@ -82,6 +82,7 @@ struct LoopAIp {
     const u64 *const *keys;  // device array: key of rotation x (packed when packed_nQ > 0, else [nd][2][nT][N] u64)
     const u64 *dig;          // [nd][dig_rows][N], shared by every x
     int nd, dig_rows, nT, packed_nQ;
+    int fp;                  // primes below 2^47: products on the FP64 pipe (bit-identical; HYDIA_LOOPA_INT_IP turns it off)
     int premul;              // keys (Q-limb rows) and the converted rows already carry P^{-1}: the combine is a plain subtraction
 };
 struct NttStore {

@@ -78,6 +78,13 @@ struct FpA {
         const double c = rint(v * W.y);
         return __fma_rn(-c, q, h) + l;
     }
+    // exact a*b - c*q for canonical a, b < q < 2^47 (no precomputed b / q): |result| <= 0.55 q
+    DEV double mulmod2(const double a, const double b) const {
+        const double h = a * b;
+        const double l = __fma_rn(a, b, -h);
+        const double c = rint(h * qinv);
+        return __fma_rn(-c, q, h) + l;
+    }
     DEV void ct(T &a, T &b, const TW W) const {
         const double r = mulmod(b, W);
         b = a - r;
@@ -296,14 +303,51 @@ DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, in
     o0 = make_ulonglong2(reduce_lazy(a0, M, la.nd), reduce_lazy(a1, M, la.nd));
     o1 = make_ulonglong2(reduce_lazy(a2, M, la.nd), reduce_lazy(a3, M, la.nd));
 }
-template <int ST>
-DEV P2Pre p2_prefetch(const NttStore &st, int xp, int j, unsigned idx, const ModC &M) {
+// the same sum for a prime below 2^47 on the FP64 pipe: every product is reduced exactly (FpA::mulmod2, 6 full-rate operations
+// against the ~12 quarter-rate integer multiplies of a 128-bit product), the three remainders add exactly, one final reduction
+// gives the canonical residue — bit-identical to the integer sum
+DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    constexpr int N = 32768;
+    const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
+    const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
+    const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
+    const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int d = 0; d < la.nd; d++) {
+        const u64 *dg = la.dig + ((size_t)d * la.dig_rows + j) * N + idx;
+        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(dg), v1 = *reinterpret_cast<const ulonglong2 *>(dg + 2);
+        const unsigned char *kd = kp + (size_t)(2 * d) * set_bytes;
+        ulonglong2 k0, k1;
+        if (six) {
+            k0 = db_load2<true, false>(kd);
+            k1 = db_load2<true, false>(kd + 12);
+        } else {
+            k0 = db_load2<false, false>(kd);
+            k1 = db_load2<false, false>(kd + 16);
+        }
+        a0 += ar.mulmod2(FpA::u2d(v0.x), FpA::u2d(k0.x));
+        a1 += ar.mulmod2(FpA::u2d(v0.y), FpA::u2d(k0.y));
+        a2 += ar.mulmod2(FpA::u2d(v1.x), FpA::u2d(k1.x));
+        a3 += ar.mulmod2(FpA::u2d(v1.y), FpA::u2d(k1.y));
+    }
+    o0 = make_ulonglong2(ar.fin_fwd(a0), ar.fin_fwd(a1));
+    o1 = make_ulonglong2(ar.fin_fwd(a2), ar.fin_fwd(a3));
+}
+DEV void loop_a_inner_product(const LoopAIp &la, const IntA &, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
+}
+DEV void loop_a_inner_product(const LoopAIp &la, const FpA &ar, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    if (la.fp) loop_a_inner_product_fp(la, ar, x, p, j, idx, o0, o1);
+    else loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
+}
+template <int ST, class A>
+DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned idx, const ModC &M) {
     constexpr size_t N = 32768;
     P2Pre r;
     r.has_ex = false;
     r.ex0 = r.ex1 = make_ulonglong2(0, 0);
     if (ST == 5) {
-        loop_a_inner_product(st.la, M, xp >> 1, xp & 1, j, idx, r.in0, r.in1);
+        loop_a_inner_product(st.la, ar, M, xp >> 1, xp & 1, j, idx, r.in0, r.in1);
     } else {
         const u64 *pi = st.in + ((size_t)xp * st.in_ls + j) * N + idx;
         r.in0 = *reinterpret_cast<const ulonglong2 *>(pi);
@@ -452,7 +496,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
             for (int hh = 0; hh < 2; hh++)
 #pragma unroll
-                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh), M);
+                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh), M);
         }
         __syncthreads();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
@@ -813,12 +857,12 @@ __global__ __launch_bounds__(1024) void k_ntt15_1p(NttTables T, const ulonglong2
                     W14b[f] = w14.y;
                 }
                 P2Pre pre = {};
-                if (ST != 0) pre = p2_prefetch<ST>(stp, xp, slot, (unsigned)((4 * h) * 4096 + 4 * t), M);
+                if (ST != 0) pre = p2_prefetch<ST>(stp, ar, xp, slot, (unsigned)((4 * h) * 4096 + 4 * t), M);
 #pragma unroll
                 for (int f = 0; f < 4; f++) {
                     const int gi = (4 * h + f) * 1024 + t;
                     P2Pre nxt = {};
-                    if (ST != 0 && f < 3) nxt = p2_prefetch<ST>(stp, xp, slot, (unsigned)(4 * (gi + 1024)), M);
+                    if (ST != 0 && f < 3) nxt = p2_prefetch<ST>(stp, ar, xp, slot, (unsigned)(4 * (gi + 1024)), M);
                     // one group at a time out of LDS: the other half's 32 values are still waiting in registers
                     double c0 = FpA::from_bits(lds[f * 128 * 33 + rd]), c1 = FpA::from_bits(lds[f * 128 * 33 + rd + 1]),
                            c2 = FpA::from_bits(lds[f * 128 * 33 + rd + 2]), c3 = FpA::from_bits(lds[f * 128 * 33 + rd + 3]);
