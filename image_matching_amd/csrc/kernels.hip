@@ -286,14 +286,16 @@ __global__ __launch_bounds__(256) void k_tensor(const ModC *__restrict__ mod, in
 // targets — (ns + nt) limb-polys of traffic instead of nt*(ns + 1)
 __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
                                                       size_t yo, u64 *__restrict__ out, size_t oo, ConvTab tab,
-                                                      LimbSel dsel) {
+                                                      LimbSel dsel, int tz) {
+    // grid.z > 1 (few polynomials: a query's fixed-cost tail): targets [z*tz, (z+1)*tz) per slice, sources re-read from L2
     const int x = blockIdx.y;
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     ulonglong2 v[HY_MAX_DIGIT];
 #pragma unroll
     for (int s = 0; s < HY_MAX_DIGIT; s++)
         if (s < tab.ns) v[s] = *reinterpret_cast<const ulonglong2 *>(y + (size_t)x * yo + (size_t)s * N + c);
-    for (int t = 0; t < tab.nt; t++) {
+    const int t_lo = blockIdx.z * tz, t_hi = min(tab.nt, t_lo + tz);
+    for (int t = t_lo; t < t_hi; t++) {
         if (t >= tab.skip_lo && t < tab.skip_hi) continue;
         const ModC M = mod[dsel.mod[t]];
         u128 ax = 0, ay = 0;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict_
 // multiply-accumulates and ONE reduction.
 __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
                                                               const u64 *__restrict__ u, u64 *__restrict__ w, int l, int nP,
-                                                              ConvTab tab) {
+                                                              ConvTab tab, int tz) {
     const int xp = blockIdx.y;
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     ulonglong2 v[HY_MAX_DIGIT];
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
     const u64 half = Ml.q >> 1;
     const bool negx = ylx > half, negy = yly > half;
     const u64 magx = negx ? Ml.q - ylx : ylx, magy = negy ? Ml.q - yly : yly;  // |centred residue|
-    for (int j = 0; j < l; j++) {
+    const int j_lo = blockIdx.z * tz, j_hi = min(l, j_lo + tz);  // grid.z slices the targets of small launches
+    for (int j = j_lo; j < j_hi; j++) {
         const ModC M = mod[j];
         u128 bx = 0, by = 0;
 #pragma unroll
@@ -787,10 +790,20 @@ void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, 
         hipLaunchKernelGGL(k_tensor<false>, dim3(N / 512, nl, X), dim3(256), 0, st, mod, N, a, b, o, nl, a_ls, b_ls,
                            (const u64 *)nullptr, 0, ScaleSel{});
 }
+// conversion kernels let one thread produce every target limb (sources read once).  With few polynomials that is N/512 * X
+// workgroups, each a long serial chain: below ~2 workgroups per CU the targets are sliced over grid.z instead (sources come from L2)
+static int small_launch_targets(int N, int X, int nt) {
+    static const bool off = getenv("HYDIA_NO_TARGET_SLICES") != nullptr;
+    const int wgs = (N / 512) * X;
+    if (off || nt <= 1 || wgs >= 512) return nt > 0 ? nt : 1;
+    const int slices = std::min(nt, (512 + wgs - 1) / wgs);
+    return (nt + slices - 1) / slices;
+}
 void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, u64 *out, size_t oo, int X,
                   const ConvTab &tab, const LimbSel &dsel) {
     ledger_add("k_base_convert", (double)X * (tab.ns + tab.nt - (tab.skip_hi - tab.skip_lo)) * LP_BYTES(N));  // sources once, every target once
-    hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel);
+    const int tz = small_launch_targets(N, X, tab.nt);
+    hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X, (tab.nt + tz - 1) / tz), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel, tz);
 }
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
                    int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl,
@@ -827,7 +840,8 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
 void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
                           const ConvTab &tab) {
     ledger_add("k_moddown_rescale_conv", (double)XP * (nP + 1 + l) * LP_BYTES(N));  // y (nP limbs) + u in, l limbs out
-    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab);
+    const int tz = small_launch_targets(N, XP, l);
+    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP, (l + tz - 1) / tz), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab, tz);
 }
 void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
                        size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl) {

@@ -1105,22 +1105,25 @@ static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u6
                (LD == 2 ? 1.0 + 1.0 / (nsl > 0 ? nsl : 1) : 2.0) * X * nsl * 262144.0);  // LD 2 reads ONE dropped limb per polynomial
     hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * nsl), dim3(256), 0, st, T, src, dst, so, dso, sel, slot0, nsl, dummy, ld);
 }
-static bool pair_polys() {  // HYDIA_NTT_NP1: one polynomial per workgroup (half the LDS, twice the twiddle loads)
+// two polynomials per workgroup share the twiddle loads; HYDIA_NTT_NP1: always one.  Small launches (below 4 workgroups per CU
+// when paired — the per-query fixed-cost tail) run one polynomial per workgroup: twice the workgroups, half the serial work in each
+static bool pair_polys(int X, int nsl) {
     static const bool v = getenv("HYDIA_NTT_NP1") == nullptr;
-    return v;
+    static const bool small_np1 = getenv("HYDIA_NTT_SMALL_PAIRS") == nullptr;
+    return v && X % 2 == 0 && (!small_np1 || (X / 2) * nsl * 16 >= 1024);
 }
 template <int ST>
 static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl,
                           const NttStore &stp) {
     {   // pass-1 output in, result out, + the epilogue's operands: acc & addend (1), rescale input (2), both + subtrahend (3)
         char name[64];
-        snprintf(name, sizeof name, "k_ntt15_p2<false, %d, %d>", (X % 2 == 0 && pair_polys()) ? 2 : 1, ST);
+        snprintf(name, sizeof name, "k_ntt15_p2<false, %d, %d>", pair_polys(X, nsl) ? 2 : 1, ST);
         double per = (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * 262144.0;
         if (ST == 5)  // pass-1 output in, result out, addend on every other polynomial, nd key rows (6- or 8-byte residues); digits from L2
             per = 2.5 * 262144.0 + stp.la.nd * 32768.0 * (stp.la.packed_nQ > 0 ? (6.0 * (nsl - 1) + 8.0) / nsl : 8.0);
         ledger_add(name, per * X * nsl);
     }
-    if (X % 2 == 0 && pair_polys())
+    if (pair_polys(X, nsl))
         hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
@@ -1183,9 +1186,9 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
             launch_1p<true, 0, 0>(st, T, src, dst, so, dso, X, sel, s0, n, scale, ld, stp);
             return;
         }
-        ledger_add((X % 2 == 0 && pair_polys()) ? "k_ntt15_p2<true, 2, 0>" : "k_ntt15_p2<true, 1, 0>", 2.0 * X * n * 262144.0);
+        ledger_add(pair_polys(X, n) ? "k_ntt15_p2<true, 2, 0>" : "k_ntt15_p2<true, 1, 0>", 2.0 * X * n * 262144.0);
         ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * n * 262144.0);
-        if (X % 2 == 0 && pair_polys())
+        if (pair_polys(X, n))
             hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
         else
             hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
