@@ -372,6 +372,8 @@ Context::~Context() {
             (void)hipEventDestroy(ev.second);
         }
     pool.trim();
+    for (auto &kv : modup_plans)
+        if (kv.second.d_tabs) (void)hipFree(kv.second.d_tabs);
     rot_keys[0] = relin_key;
     for (auto &kv : rot_keys)
         if (!kv.second.borrowed)

@@ -28,19 +28,19 @@ void Context::ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, co
     hk::ntt_inverse(stream, tabs, prm.logN, src, dst, so, dso, X, s, sc);
 }
 
-// ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
-// extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
-// NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.
-void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own, bool p1_only) {
+const Context::ModUpPlan &Context::modup_plan(int nl) {
+    auto it = modup_plans.find(nl);
+    if (it != modup_plans.end()) return it->second;
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
-    const size_t dig_x = (size_t)nd * nE * N;
     const LimbSel esel = sel_ext(nl);
-    u64 *y = pool.get((size_t)X * alpha * N * sizeof(u64));
+    ModUpPlan pl;
+    pl.nd = nd;
+    pl.inv.resize(nl);
+    std::vector<ConvTab> tabs(nd);
     for (int d = 0; d < nd; d++) {
         const int lo = d * alpha, hi = std::min(lo + alpha, nl), sz = hi - lo;
-        const LimbSel dsel = sel_range(lo, hi);
-        std::vector<u64> inv(sz);
-        ConvTab tab{};
+        ConvTab &tab = tabs[d];
+        tab = ConvTab{};
         tab.ns = sz;
         tab.nt = nE;
         tab.skip_lo = lo;
@@ -50,7 +50,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
             u64 pr = 1;
             for (int i = lo; i < hi; i++)
                 if (i != lo + s) pr = mulmod_u64(pr, q[i] % qj, qj);
-            inv[s] = invmod_u64(pr, qj);
+            pl.inv[lo + s] = invmod_u64(pr, qj);
             for (int t = 0; t < nE; t++) {
                 const u64 qt = q[esel.mod[t]];
                 u64 f = 1;
@@ -59,19 +59,49 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
                 tab.f[s][t] = f;
             }
         }
-        ntt_inv(c + (size_t)lo * N, y, c_outer, (size_t)sz * N, X, dsel, scale_of(dsel, inv, true));
+    }
+    HIP_CHECK(hipMalloc((void **)&pl.d_tabs, sizeof(ConvTab) * nd));
+    HIP_CHECK(hipMemcpy(pl.d_tabs, tabs.data(), sizeof(ConvTab) * nd, hipMemcpyHostToDevice));
+    return modup_plans.emplace(nl, std::move(pl)).first->second;
+}
+
+// ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
+// extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
+// NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.  One inverse transform and one conversion
+// launch serve all digits; the forward transforms run per digit (the digit's own limbs are skipped) unless the launch is small
+// (a query's fixed-cost tail), where one launch over every row of every digit beats nd launches that each leave most CUs idle —
+// the own rows then hold transformed garbage nobody reads (copy_own overwrites them, the inner product reads the input itself).
+void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own, bool p1_only) {
+    const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
+    const size_t dig_x = (size_t)nd * nE * N;
+    const LimbSel esel = sel_ext(nl), qsel = sel_q(nl);
+    const ModUpPlan &pl = modup_plan(nl);
+    u64 *y = pool.get((size_t)X * nl * N * sizeof(u64));
+    ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
+    const bool fused_conv = prm.logN == 15 && fuse_bconv;
+    if (!fused_conv) hk::base_convert_digits(stream, d_mod, N, y, (size_t)nl * N, dig, dig_x, X, pl.d_tabs, nd, nl, nE, esel);
+    static const bool no_merge = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
+    const bool merged = !fused_conv && !no_merge && nd > 1 && (size_t)X * nd * nE < 128;
+    if (merged) {
+        if (p1_only) hk::ntt15_forward_p1(stream, tabs, dig, dig, (size_t)nE * N, (size_t)nE * N, X * nd, esel);
+        else ntt_fwd(dig, (size_t)nE * N, X * nd, esel);
+    }
+    for (int d = 0; d < nd; d++) {
+        const int lo = d * alpha, hi = std::min(lo + alpha, nl), sz = hi - lo;
         u64 *out = dig + (size_t)d * nE * N;
         LimbSel rest{};
         rest.n = nE - hi;
         for (int t = hi; t < nE; t++) rest.mod[t - hi] = esel.mod[t];
-        if (prm.logN == 15 && fuse_bconv) {
+        if (fused_conv) {
             // (experiment switch HYDIA_FUSE_BCONV) base conversion fused into the forward NTT's first pass: measured
             // SLOWER than the separate all-targets kernel (16.8 vs 14.2 ms per 2^20 query: every target limb re-reads
             // the sources with 8-byte loads and pays its own 128-bit reduction), so it is off by default
+            ConvTab tab{};
+            HIP_CHECK(hipMemcpy(&tab, pl.d_tabs + d, sizeof(ConvTab), hipMemcpyDeviceToHost));
             NttLoad ld{};
             ld.mode = 1;
-            ld.y = y;
-            ld.y_outer = (size_t)sz * N;
+            ld.y = y + (size_t)lo * N;
+            ld.y_outer = (size_t)nl * N;
             ld.tab = tab;
             NttStore stp{};
             if (lo > 0) {
@@ -82,8 +112,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
                 ld.t0 = hi;
                 hk::ntt15_forward_fused(stream, tabs, nullptr, out + (size_t)hi * N, 0, dig_x, X, rest, ld, stp);
             }
-        } else {
-            hk::base_convert(stream, d_mod, N, y, (size_t)sz * N, out, dig_x, X, tab, esel);
+        } else if (!merged) {
             if (p1_only) {  // the caller runs the second pass fused with the inner product
                 if (lo > 0) hk::ntt15_forward_p1(stream, tabs, out, out, dig_x, dig_x, X, sel_range(0, lo));
                 if (rest.n > 0) hk::ntt15_forward_p1(stream, tabs, out + (size_t)hi * N, out + (size_t)hi * N, dig_x, dig_x, X, rest);
@@ -368,19 +397,26 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
         hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
     timer_end("ks_inner_product");
     pool.put(dig);
-    // P limbs -> coefficient form (pre-multiplied by (P/p_k)^{-1})
-    const LimbSel psel = sel_range(nQ, nT);
-    u64 *y = pool.get((size_t)XP * nP * N * sizeof(u64));
-    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, XP, psel, scale_of(psel, Phat_inv, true));
-    // limb l of the would-be ModDown output (+ d_l, doubled), to the coefficient domain
+    // limb l of the would-be ModDown output (+ d_l, doubled) replaces row l of the accumulator (nothing else reads that row), so that
+    // ONE inverse transform takes rows l .. nE-1 — the dropped limb and the special-prime limbs (pre-multiplied by (P/p_k)^{-1}) —
+    // to the coefficient domain: yu [XP][1 + nP][N], row 0 = u
     const LimbSel qsel_full = sel_q(nl);
     std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
     const ScaleSel pinv_sel = scale_of(qsel_full, pinv, false);
-    u64 *u = pool.get((size_t)XP * N * sizeof(u64));
-    hk::moddown_last_limb(stream, d_mod, N, acc, nE, c.d, c.ct_elems(), c.poly_elems(), u, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
-                          dbl ? 1 : 0);
-    const LimbSel last = sel_range(l, l + 1);
-    ntt_inv(u, u, (size_t)N, (size_t)N, XP, last, scale_ninv(last));
+    hk::moddown_last_limb(stream, d_mod, N, acc, nE, c.d, c.ct_elems(), c.poly_elems(), acc + (size_t)l * N, (size_t)nE * N, XP, l,
+                          pinv_sel.s[l], pinv_sel.s_sh[l], dbl ? 1 : 0);
+    LimbSel tail{};
+    tail.n = 1 + nP;
+    tail.mod[0] = l;
+    std::vector<u64> tail_scale(1 + nP, 1);
+    for (int k = 0; k < nP; k++) {
+        tail.mod[1 + k] = nQ + k;
+        tail_scale[1 + k] = Phat_inv[k];
+    }
+    const size_t yu_outer = (size_t)(1 + nP) * N;
+    u64 *yu = pool.get((size_t)XP * yu_outer * sizeof(u64));
+    ntt_inv(acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+    const u64 *u = yu, *y = yu + N;
     // coefficient-domain correction of every remaining limb, then ONE forward NTT per limb with the merged epilogue
     ConvTab tab{};
     tab.ns = nP;
@@ -391,7 +427,7 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
             tab.f[k][j] = dbl ? (f + f) % q[j] : f;
         }
     u64 *w = pool.get((size_t)XP * l * N * sizeof(u64));
-    hk::moddown_rescale_conv(stream, d_mod, N, y, u, w, XP, l, nP, tab);
+    hk::moddown_rescale_conv(stream, d_mod, N, y, yu_outer, u, yu_outer, w, XP, l, nP, tab);
     const LimbSel qsel = sel_q(l);
     const double out_scale = c.scale / (double)q[l];
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
@@ -418,8 +454,7 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
         for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out_scale, q[j]);
     hk::ntt15_forward_fused(stream, tabs, w, w, (size_t)l * N, (size_t)l * N, XP, qsel, ld, stp);
     pool.put(w);
-    pool.put(u);
-    pool.put(y);
+    pool.put(yu);
     pool.put(acc);
 }
 Ct Context::clone(const Ct &a) {

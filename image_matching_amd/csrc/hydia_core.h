@@ -175,6 +175,14 @@ struct Context : HostParams {
     void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 
     // ---- helpers
+    // ModUp constants of one level: per-digit conversion tables in device memory + the (D/q_j)^{-1} factors of the inverse NTT
+    struct ModUpPlan {
+        ConvTab *d_tabs = nullptr;
+        std::vector<u64> inv;
+        int nd = 0;
+    };
+    std::map<int, ModUpPlan> modup_plans;
+    const ModUpPlan &modup_plan(int nl);
     LimbSel sel_q(int nl) const;           // limbs 0..nl-1
     LimbSel sel_ext(int nl) const;         // limbs 0..nl-1 then all P limbs
     LimbSel sel_range(int lo, int hi) const;

@@ -202,6 +202,10 @@ void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, 
 // out[x][t][c] = sum_s y[x][s][c] * tab.f[s][t] mod q_{dsel.mod[t]} ; y coefficient form, residues < 2^60
 void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y_outer, u64 *out, size_t out_outer,
                   int X, const ConvTab &tab, const LimbSel &dsel);
+// ModUp of every digit in one launch: y [X][nl][N] (coefficient form, digit d = rows [d_tabs[d].skip_lo, skip_hi)) ->
+// out [X][nd][nE][N], rows of a digit's own limbs untouched; d_tabs: nd tables in device memory
+void base_convert_digits(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y_outer, u64 *out, size_t out_outer, int X,
+                          const ConvTab *d_tabs, int nd, int nl, int nE, const LimbSel &esel);
 // acc[x][p][t][c] = sum_d dig[(x*dig_x_stride) + d][t][c] * key_x[d][p][mod(t)][c];  keys[x] -> [dnum][2][nT][N]
 // (same_key: every x uses keys[0])
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dig_x_stride, int nd,
@@ -227,11 +231,11 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
 // u  [xp][N]      : INTT of (acc_l P^{-1} + d_l)(x2), the dropped limb q_l of the would-be ModDown output
 // y  [xp][nP][N]  : INTT of acc's P limbs times (P/p_k)^{-1}
 // w  [xp][l][N]   : (conv_j P^{-1})(x2) + centred(y_l) mod q_j, whose NTT is subtracted in the pass-2 epilogue (mode 3)
-void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
-                          const ConvTab &tab /* f[s][j] = (P/p_s) P^{-1} (x2) mod q_j, j <= l */);
-// u[xp][c] = (acc[xp][l][c] * pinv_l + addend[x*add_x + p*add_p + l*N + c])(x2)   (evaluation form, limb l)
+void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y_outer, const u64 *u, size_t u_outer, u64 *w, int XP,
+                          int l, int nP, const ConvTab &tab /* f[s][j] = (P/p_s) P^{-1} (x2) mod q_j, j <= l */);
+// u[xp*u_outer + c] = (acc[xp][l][c] * pinv_l + addend[x*add_x + p*add_p + l*N + c])(x2)   (evaluation form, limb l; u may be acc's row l)
 void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
-                       size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl);
+                       size_t add_p, u64 *u, size_t u_outer, int XP, int l, u64 pinv, u64 pinv_sh, int dbl);
 // rescale: t = last limb in coefficient form [X][N]; tmp[x][j][c] = centred t mod q_j (coefficient form)
 void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l);
 // out[x][j][c] = (in[x][j][c] - tmp[x][j][c]) * qlinv[j]; in has nl=l+1 limbs per x, out has l

@@ -312,6 +312,38 @@ __global__ __launch_bounds__(256) void k_base_convert(const ModC *__restrict__ m
         *reinterpret_cast<ulonglong2 *>(out + (size_t)x * oo + (size_t)t * N + c) = r;
     }
 }
+// ModUp of ALL digits of a key switch in one launch: grid (N/512, X, nd * slices).  Digit d = z / slices converts its own limbs
+// (rows [skip_lo, skip_hi) of y [X][nl][N], coefficient form) into rows of out [X][nd][nE][N]; tabs[d] lives in device memory
+__global__ __launch_bounds__(256) void k_base_convert_digits(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y, size_t yo,
+                                                             u64 *__restrict__ out, size_t oo, const ConvTab *__restrict__ tabs,
+                                                             LimbSel dsel, int slices, int tz, int nE) {
+    const int x = blockIdx.y, d = blockIdx.z / slices, zs = blockIdx.z - d * slices;
+    const ConvTab &tab = tabs[d];
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const int ns = tab.ns, lo = tab.skip_lo, hi = tab.skip_hi;
+    ulonglong2 v[HY_MAX_DIGIT];
+#pragma unroll
+    for (int s = 0; s < HY_MAX_DIGIT; s++)
+        if (s < ns) v[s] = *reinterpret_cast<const ulonglong2 *>(y + (size_t)x * yo + (size_t)(lo + s) * N + c);
+    u64 *o = out + (size_t)x * oo + (size_t)d * nE * N;
+    const int t_lo = zs * tz, t_hi = min(tab.nt, t_lo + tz);
+    for (int t = t_lo; t < t_hi; t++) {
+        if (t >= lo && t < hi) continue;
+        const ModC M = mod[dsel.mod[t]];
+        u128 ax = 0, ay = 0;
+#pragma unroll
+        for (int s = 0; s < HY_MAX_DIGIT; s++)
+            if (s < ns) {
+                const u64 f = tab.f[s][t];
+                ax += (u128)v[s].x * f;
+                ay += (u128)v[s].y * f;
+            }
+        ulonglong2 r;
+        r.x = ns <= 4 ? reduce128k(ax, M) : reduce128(ax, M);
+        r.y = ns <= 4 ? reduce128k(ay, M) : reduce128(ay, M);
+        *reinterpret_cast<ulonglong2 *>(o + (size_t)t * N + c) = r;
+    }
+}
 // two consecutive residues of an 8-byte (PK = false) or 6-byte (PK = true) row; NT: non-temporal load
 // grid (N/512, nE, X); 2 coefficients per thread, both key polys.  PK: keys[x] points at a packed key (see above)
 template <bool PK>
@@ -417,14 +449,14 @@ __global__ __launch_bounds__(256) void k_moddown_combine(const ModC *__restrict_
 // P^{-1} (and the doubling) already folded in: tab.f[s][j] = (P/p_s mod q_j) * P^{-1} (* 2) mod q_j, so a target costs nP lazy
 // multiply-accumulates and ONE reduction.
 __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__restrict__ mod, int N, const u64 *__restrict__ y,
-                                                              const u64 *__restrict__ u, u64 *__restrict__ w, int l, int nP,
-                                                              ConvTab tab, int tz) {
+                                                              size_t yo, const u64 *__restrict__ u, size_t uo, u64 *__restrict__ w,
+                                                              int l, int nP, ConvTab tab, int tz) {
     const int xp = blockIdx.y;
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     ulonglong2 v[HY_MAX_DIGIT];
 #pragma unroll
     for (int s = 0; s < HY_MAX_DIGIT; s++)
-        if (s < nP) v[s] = *reinterpret_cast<const ulonglong2 *>(y + ((size_t)xp * nP + s) * N + c);
+        if (s < nP) v[s] = *reinterpret_cast<const ulonglong2 *>(y + (size_t)xp * yo + (size_t)s * N + c);
     // the dropped limb of the ModDown output, coefficient form: y_l = u - conv_l P^{-1} (doubled when dbl)
     const ModC Ml = mod[l];
     u128 ax = 0, ay = 0;
@@ -434,7 +466,7 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
             ax += (u128)v[s].x * tab.f[s][l];
             ay += (u128)v[s].y * tab.f[s][l];
         }
-    const ulonglong2 uu = *reinterpret_cast<const ulonglong2 *>(u + (size_t)xp * N + c);
+    const ulonglong2 uu = *reinterpret_cast<const ulonglong2 *>(u + (size_t)xp * uo + c);
     const u64 ylx = submod(uu.x, (nP <= 4 ? reduce128k(ax, Ml) : reduce128(ax, Ml)), Ml.q), yly = submod(uu.y, (nP <= 4 ? reduce128k(ay, Ml) : reduce128(ay, Ml)), Ml.q);
     const u64 half = Ml.q >> 1;
     const bool negx = ylx > half, negy = yly > half;
@@ -457,9 +489,9 @@ __global__ __launch_bounds__(256) void k_moddown_rescale_conv(const ModC *__rest
     }
 }
 // grid (N/512, XP)
-__global__ __launch_bounds__(256) void k_moddown_last_limb(const ModC *__restrict__ mod, int N, const u64 *__restrict__ acc,
+__global__ __launch_bounds__(256) void k_moddown_last_limb(const ModC *__restrict__ mod, int N, const u64 *acc,  // u may be acc's row l
                                                            int acc_limbs, const u64 *__restrict__ addend, size_t add_x,
-                                                           size_t add_p, u64 *__restrict__ u, int l, u64 pinv, u64 pinv_sh,
+                                                           size_t add_p, u64 *u, size_t uo, int l, u64 pinv, u64 pinv_sh,
                                                            int dbl) {
     const int xp = blockIdx.y, x = xp >> 1, p = xp & 1;
     const u64 q = mod[l].q;
@@ -473,7 +505,7 @@ __global__ __launch_bounds__(256) void k_moddown_last_limb(const ModC *__restric
         r.x = addmod(r.x, r.x, q);
         r.y = addmod(r.y, r.y, q);
     }
-    *reinterpret_cast<ulonglong2 *>(u + (size_t)xp * N + c) = r;
+    *reinterpret_cast<ulonglong2 *>(u + (size_t)xp * uo + c) = r;
 }
 // grid (N/256, l, X)
 __global__ __launch_bounds__(256) void k_rescale_spread(const ModC *__restrict__ mod, int N, const u64 *__restrict__ t,
@@ -805,6 +837,13 @@ void base_convert(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t y
     const int tz = small_launch_targets(N, X, tab.nt);
     hipLaunchKernelGGL(k_base_convert, dim3(N / 512, X, (tab.nt + tz - 1) / tz), dim3(256), 0, st, mod, N, y, yo, out, oo, tab, dsel, tz);
 }
+void base_convert_digits(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, u64 *out, size_t oo, int X,
+                          const ConvTab *d_tabs, int nd, int nl, int nE, const LimbSel &esel) {
+    ledger_add("k_base_convert_digits", (double)X * nd * nE * LP_BYTES(N));  // nl sources once + (nd nE - nl) targets once
+    const int tz = small_launch_targets(N, X * nd, nE);
+    const int slices = (nE + tz - 1) / tz;
+    hipLaunchKernelGGL(k_base_convert_digits, dim3(N / 512, X, nd * slices), dim3(256), 0, st, mod, N, y, yo, out, oo, d_tabs, esel, slices, tz, nE);
+}
 void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_t dxs, int nd, const u64 *const *keys,
                    int same_key, int nT, u64 *acc, int X, const LimbSel &esel, const u64 *own, size_t own_xs, int alpha, int nl,
                    int acc_rows, int packed_nQ, int dig_rows, int dig_t0) {
@@ -837,16 +876,16 @@ void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, 
     hipLaunchKernelGGL(k_moddown_combine, dim3((1 << logN) / 256, nl, X * 2), dim3(256), 0, st, mod, logN, acc, acc_limbs,
                        conv, addend, axs, aps, add_polys, out, nl, pinv, galois, same_g);
 }
-void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, const u64 *u, u64 *w, int XP, int l, int nP,
-                          const ConvTab &tab) {
+void moddown_rescale_conv(hipStream_t st, const ModC *mod, int N, const u64 *y, size_t yo, const u64 *u, size_t uo, u64 *w, int XP, int l,
+                          int nP, const ConvTab &tab) {
     ledger_add("k_moddown_rescale_conv", (double)XP * (nP + 1 + l) * LP_BYTES(N));  // y (nP limbs) + u in, l limbs out
     const int tz = small_launch_targets(N, XP, l);
-    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP, (l + tz - 1) / tz), dim3(256), 0, st, mod, N, y, u, w, l, nP, tab, tz);
+    hipLaunchKernelGGL(k_moddown_rescale_conv, dim3(N / 512, XP, (l + tz - 1) / tz), dim3(256), 0, st, mod, N, y, yo, u, uo, w, l, nP, tab, tz);
 }
 void moddown_last_limb(hipStream_t st, const ModC *mod, int N, const u64 *acc, int acc_limbs, const u64 *addend, size_t add_x,
-                       size_t add_p, u64 *u, int XP, int l, u64 pinv, u64 pinv_sh, int dbl) {
+                       size_t add_p, u64 *u, size_t uo, int XP, int l, u64 pinv, u64 pinv_sh, int dbl) {
     ledger_add("k_moddown_last_limb", 3.0 * XP * LP_BYTES(N));
-    hipLaunchKernelGGL(k_moddown_last_limb, dim3(N / 512, XP), dim3(256), 0, st, mod, N, acc, acc_limbs, addend, add_x, add_p, u, l,
+    hipLaunchKernelGGL(k_moddown_last_limb, dim3(N / 512, XP), dim3(256), 0, st, mod, N, acc, acc_limbs, addend, add_x, add_p, u, uo, l,
                        pinv, pinv_sh, dbl);
 }
 void rescale_spread(hipStream_t st, const ModC *mod, int N, const u64 *t, u64 *tmp, int X, int l) {
