@@ -444,8 +444,22 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     unsigned g = 1u;
     if ((ST == 1 || ST == 5) && st.ginv) g = st.ginv[st.same_g ? 0 : (xp >> 1)];
     if (g != 1u) {
+        // In bit-reversed order the automorphism maps the aligned group of four {idx .. idx+3} onto ONE aligned group of four: the two
+        // low index bits are the two high bits of brev(c), they only move the two high bits of e (g is odd), i.e. the two low bits of
+        // the target.  So the lane permutes its four values in registers and stores 32 contiguous bytes instead of scattering four
+        // 8-byte words: value k lands at base + brev2((t0 + brev2(k) g) mod 4), hence slot j holds k = brev2(((brev2(j) - t0) g) mod 4)
+        const unsigned o0 = perm_idx(idx, g), base = o0 & ~3u;
+        const unsigned t0 = ((o0 & 1u) << 1) | ((o0 >> 1) & 1u);
+        u64 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) o[perm_idx(idx + k, g)] = r[k];
+        for (unsigned jj = 0; jj < 4; jj++) {
+            const unsigned bj = ((jj & 1u) << 1) | (jj >> 1);
+            const unsigned kb = ((bj - t0) * g) & 3u;  // = brev2(k): bit 1 of kb is bit 0 of k
+            const u64 lo = (kb & 1u) ? r[2] : r[0], hi = (kb & 1u) ? r[3] : r[1];  // k bit 1 = kb bit 0
+            w[jj] = (kb & 2u) ? hi : lo;                                           // k bit 0 = kb bit 1
+        }
+        *reinterpret_cast<ulonglong2 *>(o + base) = make_ulonglong2(w[0], w[1]);
+        *reinterpret_cast<ulonglong2 *>(o + base + 2) = make_ulonglong2(w[2], w[3]);
     } else {
         *reinterpret_cast<ulonglong2 *>(o + idx) = make_ulonglong2(r[0], r[1]);
         *reinterpret_cast<ulonglong2 *>(o + idx + 2) = make_ulonglong2(r[2], r[3]);
