@@ -154,13 +154,28 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
                 for (int j = 0; j < nl; j++) tab.f[k][j] = mulmod_u64(Phat_mod_q[k][j], Pinv_mod_q[j], q[j]);
         {
             const int x0 = 0, Xc = X;
-            u64 *accp = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
-            timer_begin("ks_inner_product");
-            hk::inner_product(stream, d_mod, N, dig, 0, nd, d_keys + x0, 0, nT, accp, Xc, psel, nullptr, 0, 1, 0, nP, keys_packed_nQ, nE, nl);
-            timer_end("ks_inner_product");
             u64 *y = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
-            ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true));
-            pool.put(accp);
+            static const bool ip_in_intt = getenv("HYDIA_LOOPA_SEPARATE_IP") == nullptr;
+            if (ip_in_intt) {
+                // the special-prime limbs of <digits, key> are formed in the load of the ModDown inverse transform (never in HBM)
+                LoopAIp lp{};
+                lp.keys = d_keys + x0;
+                lp.dig = dig;
+                lp.nd = nd;
+                lp.dig_rows = nE;
+                lp.nT = nT;
+                lp.packed_nQ = keys_packed_nQ;
+                lp.key_row0 = nQ;
+                lp.dig_row0 = nl;
+                hk::ntt15_inverse_loop_a(stream, tabs, y, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true), lp);
+            } else {
+                u64 *accp = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
+                timer_begin("ks_inner_product");
+                hk::inner_product(stream, d_mod, N, dig, 0, nd, d_keys + x0, 0, nT, accp, Xc, psel, nullptr, 0, 1, 0, nP, keys_packed_nQ, nE, nl);
+                timer_end("ks_inner_product");
+                ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true));
+                pool.put(accp);
+            }
             u64 *conv = pool.get((size_t)Xc * 2 * nl * N * sizeof(u64));
             hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, Xc * 2, tab, qsel);
             pool.put(y);

@@ -82,6 +82,8 @@ struct LoopAIp {
     const u64 *const *keys;  // device array: key of rotation x (packed when packed_nQ > 0, else [nd][2][nT][N] u64)
     const u64 *dig;          // [nd][dig_rows][N], shared by every x
     int nd, dig_rows, nT, packed_nQ;
+    int key_row0, dig_row0;  // limb slot s of the launch <-> key row key_row0 + s, digit row dig_row0 + s (0, 0 for the Q limbs;
+                             // nQ, nl for the special-prime limbs whose sums enter the ModDown inverse transform directly)
     int fp;                  // primes below 2^47: products on the FP64 pipe (bit-identical; HYDIA_LOOPA_INT_IP turns it off)
     int premul;              // keys (Q-limb rows) and the converted rows already carry P^{-1}: the combine is a plain subtraction
 };
@@ -166,6 +168,9 @@ void ntt_inverse(hipStream_t st, const NttTables &T, int logN, const u64 *src, u
 // N = 2^15 register-radix fast path (ntt15.hip); ntt_forward / ntt_inverse dispatch to it when logN == 15
 void ntt15_forward(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X,
                    const LimbSel &sel);
+// inverse transform whose INPUT is loop A's inner product over the limbs of sel (formed in the first pass's load, never in HBM)
+void ntt15_inverse_loop_a(hipStream_t st, const NttTables &T, u64 *dst, size_t dst_outer, int X, const LimbSel &sel,
+                          const ScaleSel &scale, const LoopAIp &la);
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X,
                    const LimbSel &sel, const ScaleSel &scale);
 // forward transform with fused prologue / epilogue; dst is the [X][sel.n][N] scratch between the passes

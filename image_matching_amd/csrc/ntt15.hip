@@ -276,15 +276,16 @@ struct P2Pre {
 };
 // mode 5: the accumulator value of 4 consecutive coefficients of limb j, key polynomial p, rotation x — formed here instead of
 // being read back: nd lazy 128-bit products per coefficient, one reduction
-DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     constexpr int N = 32768;
     const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
+    const int j = la.key_row0 + slot, jd = la.dig_row0 + slot;
     const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
     const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
     const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
     u128 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int d = 0; d < la.nd; d++) {
-        const u64 *dg = la.dig + ((size_t)d * la.dig_rows + j) * N + idx;
+        const u64 *dg = la.dig + ((size_t)d * la.dig_rows + jd) * N + idx;
         const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(dg), v1 = *reinterpret_cast<const ulonglong2 *>(dg + 2);
         const unsigned char *kd = kp + (size_t)(2 * d) * set_bytes;
         ulonglong2 k0, k1;
@@ -306,15 +307,16 @@ DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, in
 // the same sum for a prime below 2^47 on the FP64 pipe: every product is reduced exactly (FpA::mulmod2, 6 full-rate operations
 // against the ~12 quarter-rate integer multiplies of a 128-bit product), the three remainders add exactly, one final reduction
 // gives the canonical residue — bit-identical to the integer sum
-DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     constexpr int N = 32768;
     const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
+    const int j = la.key_row0 + slot, jd = la.dig_row0 + slot;
     const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
     const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
     const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int d = 0; d < la.nd; d++) {
-        const u64 *dg = la.dig + ((size_t)d * la.dig_rows + j) * N + idx;
+        const u64 *dg = la.dig + ((size_t)d * la.dig_rows + jd) * N + idx;
         const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(dg), v1 = *reinterpret_cast<const ulonglong2 *>(dg + 2);
         const unsigned char *kd = kp + (size_t)(2 * d) * set_bytes;
         ulonglong2 k0, k1;
@@ -613,8 +615,13 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                const ulonglong2 i0 = *reinterpret_cast<const ulonglong2 *>(s[p] + e);
-                const ulonglong2 i1 = *reinterpret_cast<const ulonglong2 *>(s[p] + e + 2);
+                ulonglong2 i0, i1;
+                if (ST == 5) {  // the transform's input is loop A's inner product for these four coefficients
+                    loop_a_inner_product(stp.la, ar, M, (xp0 + p) >> 1, (xp0 + p) & 1, slot, (unsigned)(B0 + e), i0, i1);
+                } else {
+                    i0 = *reinterpret_cast<const ulonglong2 *>(s[p] + e);
+                    i1 = *reinterpret_cast<const ulonglong2 *>(s[p] + e + 2);
+                }
                 T c0 = ar.from_canon(i0.x), c1 = ar.from_canon(i0.y), c2 = ar.from_canon(i1.x), c3 = ar.from_canon(i1.y);
                 ar.gs(c0, c1, W14a);
                 ar.gs(c2, c3, W14b);
@@ -1189,6 +1196,27 @@ void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64
     else if (stp.mode == 2) forward_runs<0, 2>(st, T, src, dst, so, dso, X, sel, ld, stp);
     else if (stp.mode == 3) forward_runs<0, 3>(st, T, src, dst, so, dso, X, sel, ld, stp);
     else forward_runs<0, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);
+}
+void ntt15_inverse_loop_a(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const ScaleSel &scale,
+                          const LoopAIp &la) {
+    NttLoad ld{};
+    NttStore stp{};
+    stp.mode = 5;
+    stp.la = la;
+    {   // per limb-polynomial: nd key rows (8-byte residues: special primes; 6-byte where packed) in, raw pass-2' image out
+        double keyb = 0;
+        for (int s = 0; s < sel.n; s++) {
+            const int j = la.key_row0 + s;
+            keyb += la.nd * 32768.0 * ((la.packed_nQ > 0 && j > 0 && j < la.packed_nQ) ? 6.0 : 8.0);
+        }
+        ledger_add((X % 2 == 0) ? "k_ntt15_p2<true, 2, 5>" : "k_ntt15_p2<true, 1, 5>", (double)X * (keyb + sel.n * 262144.0));
+        ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * sel.n * 262144.0);
+    }
+    if (X % 2 == 0)
+        hipLaunchKernelGGL((k_ntt15_p2<true, 2, 5>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, stp);
+    else
+        hipLaunchKernelGGL((k_ntt15_p2<true, 1, 5>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, stp);
+    hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, scale, ld);
 }
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                    const LimbSel &sel, const ScaleSel &scale) {
