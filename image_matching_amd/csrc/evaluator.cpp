@@ -80,7 +80,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
     ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
     const bool fused_conv = prm.logN == 15 && fuse_bconv;
     if (!fused_conv) hk::base_convert_digits(stream, d_mod, N, y, (size_t)nl * N, dig, dig_x, X, pl.d_tabs, nd, nl, nE, esel);
-    static const bool no_merge = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
+    const bool no_merge = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
     const bool merged = !fused_conv && !no_merge && nd > 1 && (size_t)X * nd * nE < 128;
     if (merged) {
         if (p1_only) hk::ntt15_forward_p1(stream, tabs, dig, dig, (size_t)nE * N, (size_t)nE * N, X * nd, esel);
@@ -155,7 +155,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
         {
             const int x0 = 0, Xc = X;
             u64 *y = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
-            static const bool ip_in_intt = getenv("HYDIA_LOOPA_SEPARATE_IP") == nullptr;
+            const bool ip_in_intt = getenv("HYDIA_LOOPA_SEPARATE_IP") == nullptr;
             if (ip_in_intt) {
                 // the special-prime limbs of <digits, key> are formed in the load of the ModDown inverse transform (never in HBM)
                 LoopAIp lp{};
@@ -404,10 +404,17 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
     modup_digits(c2, c.ct_elems(), X, nl, dig, /*copy_own=*/false, /*p1_only=*/fip);
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
+    // yu [XP][1 + nP][N]: row 0 = the dropped limb u, rows 1.. = the special-prime limbs, on their way to the coefficient domain
+    const size_t yu_outer = (size_t)(1 + nP) * N;
+    u64 *yu = pool.get((size_t)XP * yu_outer * sizeof(u64));
+    // with the fused inner product the special-prime sums never reach acc: the kernel runs the first pass of their inverse
+    // transform itself and leaves its raw image in yu (HYDIA_RELIN_SEPARATE_INTT: through acc, as before)
+    const bool tail_in_ip = getenv("HYDIA_RELIN_SEPARATE_INTT") == nullptr;
+    const bool fused_tail = fip && tail_in_ip && prm.logN == 15;
     timer_begin("ks_inner_product");
     if (fip)
         hk::ntt15_p2_inner_product(stream, tabs, d_mod, dig, (size_t)nd * nE * N, nd, X, nl, nP, nT, alpha, relin_key.d_cell, relin_key.d, c2,
-                                   c.ct_elems(), acc);
+                                   c.ct_elems(), acc, fused_tail ? yu : nullptr, yu_outer, 1);
     else
         hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
     timer_end("ks_inner_product");
@@ -428,9 +435,12 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
         tail.mod[1 + k] = nQ + k;
         tail_scale[1 + k] = Phat_inv[k];
     }
-    const size_t yu_outer = (size_t)(1 + nP) * N;
-    u64 *yu = pool.get((size_t)XP * yu_outer * sizeof(u64));
-    ntt_inv(acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+    if (fused_tail) {
+        hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, sel_range(l, l + 1));
+        hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+    } else {
+        ntt_inv(acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+    }
     const u64 *u = yu, *y = yu + N;
     // coefficient-domain correction of every remaining limb, then ONE forward NTT per limb with the merged epilogue
     ConvTab tab{};

@@ -75,6 +75,11 @@ struct IpArgs {
     const u64 *c2;    // [x][..][N] the polynomial being key-switched, limb t at c2 + x*c2_xs + t*N
     size_t c2_xs;
     u64 *acc;         // [x][2][nE][N]
+    // special-prime limbs only (kernel variant TAIL): the two sums do not go to acc but straight through the first pass of their
+    // inverse transform; its raw image lands in row inv_row0 + (t - nl) of polynomial 2x + {0,1} of inv_out
+    u64 *inv_out;
+    size_t inv_outer;  // elements per polynomial of inv_out
+    int inv_row0;
 };
 // store mode 5 = mode 1 whose `in` operand (the key-switching accumulator of the Q limbs) is never materialised: the epilogue forms
 // sum_d dig[d][j][c] * key_x[d][p][j][c] itself from the shared digits (L2-resident) and rotation x's key (loop A)
@@ -221,10 +226,15 @@ void inner_product(hipStream_t st, const ModC *mod, int N, const u64 *dig, size_
 size_t key_packed_bytes(int N, int nQ, int nT, int nd);
 // premul (optional): per-modulus factor applied to the Q-limb rows while packing (P^{-1} mod q_j for the fused loop A)
 void key_pack(hipStream_t st, const ModC *mod, int N, int nQ, int nT, int nd, const u64 *key, void *out, const ScaleSel *premul = nullptr);
+// the two halves of ntt15_inverse on their own (the fused key-switching tail runs the first pass of some rows elsewhere)
+void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X, const LimbSel &sel);
+void ntt15_inverse_p1(hipStream_t st, const NttTables &T, u64 *dst, size_t dst_outer, int X, const LimbSel &sel, const ScaleSel &scale);
 // second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every
-// extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2)
+// extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2).
+// inv_out != nullptr: the special-prime rows skip acc (see IpArgs)
 void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,
-                            int nl, int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc);
+                            int nl, int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
+                            u64 *inv_out = nullptr, size_t inv_outer = 0, int inv_row0 = 0);
 void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel);
 // out[x][p][j][c'] = ((acc[x][p][j][c] - conv[x][p][j][c]) * pinv[j] + (addend ? addend[x*add_x + p*add_ps + j*N + c] : 0)),
 // c = perm_g(c') when galois[x] != 1 (evaluation-form automorphism), acc rows have stride acc_limbs*N

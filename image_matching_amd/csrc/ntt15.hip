@@ -468,12 +468,83 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     }
 }
 
+// phases B' and A' of the inverse second pass for NPI polynomials whose phase-C' output sits in lds (caller synchronised)
+template <class A, int NPI>
+DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[8 * 288], u64 *const *d, int t, int B0) {
+    typedef typename A::T T;
+    typedef typename A::TW TW;
+    constexpr int NP = NPI;
+    constexpr int LROW = 36, LBLK = 8 * LROW;
+    const int blk = t >> 5, w = t & 31;
+    const int bg = (B0 >> 8) + blk;
+    const int a = w >> 2, b = w & 3;
+    T v[NP][8];
+    // phase B': strides 4, 8, 16
+    {
+        const int ib = 8 * bg + a;
+        const TW W10 = A::tw(tw[1024 + ib]);
+        const TW W11a = A::tw(tw[2048 + 2 * ib]), W11b = A::tw(tw[2048 + 2 * ib + 1]);
+        TW W12[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + a * LROW + 4 * k + b]);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W12[k >> 1]);
+            ar.gs(v[p][0], v[p][2], W11a);
+            ar.gs(v[p][1], v[p][3], W11a);
+            ar.gs(v[p][4], v[p][6], W11b);
+            ar.gs(v[p][5], v[p][7], W11b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W10);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                ar.recentre(v[p][k]);
+                lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
+            }
+        }
+    }
+    __syncthreads();
+    // phase A': strides 32, 64, 128
+    {
+        const TW W7 = A::tw(tw[128 + bg]);
+        const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
+        TW W9[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + k * LROW + w]);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W9[k >> 1]);
+            ar.gs(v[p][0], v[p][2], W8a);
+            ar.gs(v[p][1], v[p][3], W8a);
+            ar.gs(v[p][4], v[p][6], W8b);
+            ar.gs(v[p][5], v[p][7], W8b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W7);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                ar.recentre_wide(v[p][k]);
+                d[p][blk * 256 + 32 * k + w] = A::to_bits(v[p][k]);  // raw: pass 1' finishes
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ pass 2 (contiguous)
 // 256 threads: blk = t>>5, w = t&31.  NP polynomials (1 or 2, same modulus) share every twiddle load.  LDS rows of 32
 // coefficients are padded to 36 so phase B's (a, b) reads hit 64 distinct banks.
+// ST 6 = ST 4 for the special-prime limbs with the inverse transform's second pass appended: the two sums of a lane's four
+// coefficients go through phase C' in registers and meet the other lanes' in lds[0], lds[1] (the digits' images there are dead by
+// then: every lane reads and overwrites only its own four slots), phases B', A' follow, the raw image leaves through dinv.
 template <class A, bool INV, int NP, int ST>
 DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const *s, u64 *const *d, u64 (*lds)[8 * 288], int t,
-                 int B0, const NttStore &stp, const ModC &M, int xp0, int slot) {
+                 int B0, const NttStore &stp, const ModC &M, int xp0, int slot, const ulonglong2 *__restrict__ itw = nullptr,
+                 u64 *const *dinv = nullptr) {
     typedef typename A::T T;
     typedef typename A::TW TW;
     constexpr int LROW = 36, LBLK = 8 * LROW;
@@ -536,7 +607,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         // instead of 136 / 150 registers, i.e. 4 instead of 3 waves per SIMD (-0.4 ms per query at 2^14, -0.8 ms at 2^20)
         constexpr bool SPLIT = ST == 5 || ST == 3;
         P2Pre pre[2][NP];
-        if (ST != 0 && ST != 4) {
+        if (ST != 0 && ST != 4 && ST != 6) {
 #pragma unroll
             for (int hh = 0; hh < (SPLIT ? 1 : 2); hh++)
 #pragma unroll
@@ -565,7 +636,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 ar.ct(c1, c3, W13);
                 ar.ct(c0, c1, W14a);
                 ar.ct(c2, c3, W14b);
-                if (ST == 4) {
+                if (ST == 4 || ST == 6) {
                     const typename IpAcc<A>::V vv[4] = {IpAcc<A>::prep(ar, c0), IpAcc<A>::prep(ar, c1), IpAcc<A>::prep(ar, c2), IpAcc<A>::prep(ar, c3)};
                     const int dgt = p >= ip_own ? p + 1 : p;
                     const u64 *kb = stp.ip.key + (((size_t)dgt * 2) * stp.ip.nT + ip_m) * 32768 + (B0 + e);
@@ -585,7 +656,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[SPLIT ? 0 : hh][p]);
                 }
             }
-            if (ST == 4) {
+            if (ST == 4 || ST == 6) {
                 const size_t ci = (size_t)(B0 + e);
                 if (ip_own < (1 << 30)) {
                     const u64 *cv = stp.ip.c2 + (size_t)xp0 * stp.ip.c2_xs + (size_t)ip_t * 32768 + ci;
@@ -598,6 +669,23 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     ipb[0].mac(ar, ov[0], b0.x); ipb[1].mac(ar, ov[1], b0.y); ipb[2].mac(ar, ov[2], b1.x); ipb[3].mac(ar, ov[3], b1.y);
                     ipa[0].mac(ar, ov[0], a0.x); ipa[1].mac(ar, ov[1], a0.y); ipa[2].mac(ar, ov[2], a1.x); ipa[3].mac(ar, ov[3], a1.y);
                 }
+                if (ST == 6) {
+                    const TW I13 = A::tw(itw[8192 + gi]), I14a = A::tw(itw[16384 + 2 * gi]), I14b = A::tw(itw[16384 + 2 * gi + 1]);
+#pragma unroll
+                    for (int pp = 0; pp < 2; pp++) {
+                        IpAcc<A> *ip = pp == 0 ? ipb : ipa;
+                        T c0 = ar.from_canon(ip[0].fin(ar, M, NP + 1)), c1 = ar.from_canon(ip[1].fin(ar, M, NP + 1)),
+                          c2 = ar.from_canon(ip[2].fin(ar, M, NP + 1)), c3 = ar.from_canon(ip[3].fin(ar, M, NP + 1));
+                        ar.gs(c0, c1, I14a);
+                        ar.gs(c2, c3, I14b);
+                        ar.gs(c0, c2, I13);
+                        ar.gs(c1, c3, I13);
+                        ar.recentre_wide(c0); ar.recentre_wide(c1); ar.recentre_wide(c2); ar.recentre_wide(c3);
+                        lds[pp][la] = A::to_bits(c0); lds[pp][la + 1] = A::to_bits(c1);
+                        lds[pp][la + 2] = A::to_bits(c2); lds[pp][la + 3] = A::to_bits(c3);
+                    }
+                    continue;
+                }
                 u64 *ob = stp.ip.acc + (((size_t)xp0 * 2) * stp.ip.nE + ip_t) * 32768 + ci;
                 u64 *oa = ob + (size_t)stp.ip.nE * 32768;
                 *reinterpret_cast<ulonglong2 *>(ob) = make_ulonglong2(ipb[0].fin(ar, M, NP + 1), ipb[1].fin(ar, M, NP + 1));
@@ -605,6 +693,10 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 *reinterpret_cast<ulonglong2 *>(oa) = make_ulonglong2(ipa[0].fin(ar, M, NP + 1), ipa[1].fin(ar, M, NP + 1));
                 *reinterpret_cast<ulonglong2 *>(oa + 2) = make_ulonglong2(ipa[2].fin(ar, M, NP + 1), ipa[3].fin(ar, M, NP + 1));
             }
+        }
+        if (ST == 6) {
+            __syncthreads();
+            p2_inverse_BA<A, 2>(ar, itw, lds, dinv, t, B0);
         }
     } else {
         // phase C': strides 1, 2
@@ -633,60 +725,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             }
         }
         __syncthreads();
-        // phase B': strides 4, 8, 16
-        {
-            const int ib = 8 * bg + a;
-            const TW W10 = A::tw(tw[1024 + ib]);
-            const TW W11a = A::tw(tw[2048 + 2 * ib]), W11b = A::tw(tw[2048 + 2 * ib + 1]);
-            TW W12[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + a * LROW + 4 * k + b]);
-#pragma unroll
-                for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W12[k >> 1]);
-                ar.gs(v[p][0], v[p][2], W11a);
-                ar.gs(v[p][1], v[p][3], W11a);
-                ar.gs(v[p][4], v[p][6], W11b);
-                ar.gs(v[p][5], v[p][7], W11b);
-#pragma unroll
-                for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W10);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    ar.recentre(v[p][k]);
-                    lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
-                }
-            }
-        }
-        __syncthreads();
-        // phase A': strides 32, 64, 128
-        {
-            const TW W7 = A::tw(tw[128 + bg]);
-            const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
-            TW W9[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + k * LROW + w]);
-#pragma unroll
-                for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W9[k >> 1]);
-                ar.gs(v[p][0], v[p][2], W8a);
-                ar.gs(v[p][1], v[p][3], W8a);
-                ar.gs(v[p][4], v[p][6], W8b);
-                ar.gs(v[p][5], v[p][7], W8b);
-#pragma unroll
-                for (int k = 0; k < 4; k++) ar.gs(v[p][k], v[p][k + 4], W7);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    ar.recentre_wide(v[p][k]);
-                    d[p][blk * 256 + 32 * k + w] = A::to_bits(v[p][k]);  // raw: pass 1' finishes
-                }
-            }
-        }
+        p2_inverse_BA<A, NP>(ar, tw, lds, d, t, B0);
     }
 }
 
@@ -715,10 +754,10 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
 
 // second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
 // workgroups that share a key tile follow each other.  Limb t = t0 + slot; the NP digits are all digits but the limb's own.
-template <int NP, bool OWN>
+template <int NP, bool OWN, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
     constexpr int N = 32768;
-    __shared__ u64 lds[NP][8 * 288];
+    __shared__ u64 lds[(TAIL && NP < 2) ? 2 : NP][8 * 288];
     const int y = blockIdx.y, slot = y / X, x = y - slot * X, t = t0 + slot;
     const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
     const ModC M = T.mod[m];
@@ -733,6 +772,16 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__r
         const int dgt = p >= own_d ? p + 1 : p;
         s[p] = dig + (size_t)x * dxs + ((size_t)dgt * stp.ip.nE + t) * N + B0;
         d[p] = nullptr;
+    }
+    if (TAIL) {
+        const ulonglong2 *__restrict__ itw = (fp ? T.itwf : T.itwp) + (size_t)m * N;
+        u64 *dinv[2];
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++)
+            dinv[pp] = stp.ip.inv_out + (size_t)(2 * x + pp) * stp.ip.inv_outer + (size_t)(stp.ip.inv_row0 + t - stp.ip.nl) * N + B0;
+        if (fp) p2_body<FpA, false, NP, 6>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        else p2_body<IntA, false, NP, 6>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        return;
     }
     if (fp) p2_body<FpA, false, NP, 4>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
     else p2_body<IntA, false, NP, 4>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
@@ -1023,7 +1072,8 @@ __global__ __launch_bounds__(1024) void k_ntt15_1p(NttTables T, const ulonglong2
 namespace hk {
 
 void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dxs, int nd, int X, int nl,
-                            int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc) {
+                            int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
+                            u64 *inv_out, size_t inv_outer, int inv_row0) {
     const int nE = nl + nP;
     NttStore stp{};
     stp.mode = 4;
@@ -1036,14 +1086,17 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     stp.ip.c2 = c2;
     stp.ip.c2_xs = c2_xs;
     stp.ip.acc = acc;
+    stp.ip.inv_out = inv_out;
+    stp.ip.inv_outer = inv_outer;
+    stp.ip.inv_row0 = inv_row0;
     if (nd >= 2) {  // NP pass-1 digits in (+ the limb's own residues), two accumulator rows out; the key tiles are shared by all x (L2)
         char name[64];
-        snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, true>", nd - 1 > 3 ? 3 : nd - 1);
+        snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, true, false>", nd - 1 > 3 ? 3 : nd - 1);
         ledger_add(name, ((nd - 1) + 1 + 2.0) * nl * X * 262144.0);
     }
     {
         char name[64];
-        snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, false>", nd > 4 ? 4 : nd);
+        snprintf(name, sizeof name, inv_out ? "k_ntt15_p2_ip<%d, false, true>" : "k_ntt15_p2_ip<%d, false, false>", nd > 4 ? 4 : nd);
         ledger_add(name, (nd + 2.0) * nP * X * 262144.0);
     }
     // Q limbs: nd - 1 digits are transformed, the limb's own digit is read from c2
@@ -1060,6 +1113,13 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
         hipLaunchKernelGGL((k_ntt15_p2_ip<3, true>), dim3(16, nl * X), dim3(256), 0, st, T, dig, dxs, X, 0, stp);
     }
     // P limbs: every digit is transformed
+    if (inv_out) {
+        if (nd == 1) hipLaunchKernelGGL((k_ntt15_p2_ip<1, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+        else if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip<2, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+        else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip<3, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+        else hipLaunchKernelGGL((k_ntt15_p2_ip<4, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+        return;
+    }
     if (nd == 1) hipLaunchKernelGGL((k_ntt15_p2_ip<1, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
     else if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip<2, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
     else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip<3, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
@@ -1216,6 +1276,20 @@ void ntt15_inverse_loop_a(hipStream_t st, const NttTables &T, u64 *dst, size_t d
         hipLaunchKernelGGL((k_ntt15_p2<true, 2, 5>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<true, 1, 5>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, stp);
+    hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, scale, ld);
+}
+void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel) {
+    NttStore stp{};
+    const bool pair = pair_polys(X, sel.n);
+    ledger_add(pair ? "k_ntt15_p2<true, 2, 0>" : "k_ntt15_p2<true, 1, 0>", 2.0 * X * sel.n * 262144.0);
+    if (pair)
+        hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, 0, sel.n, stp);
+    else
+        hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, 0, sel.n, stp);
+}
+void ntt15_inverse_p1(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const ScaleSel &scale) {
+    NttLoad ld{};
+    ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * sel.n * 262144.0);
     hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, scale, ld);
 }
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,

@@ -286,6 +286,9 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         {"HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "3"},
         {"HYDIA_NTT_1PASS": "1", "HYDIA_NTT_1PASS_MIN": "1"},  # the one-pass kernel (one HBM round trip) for every FP64 limb transform
         {"HYDIA_NTT_1PASS": "1"},  # ... only for launches of at least 1024 limb-polynomials
+        # round-2 fusions switched off one group at a time: per-digit ModUp launches, loop A's special-prime inner product as its own
+        # kernel, the relinearisation's special-prime rows through the accumulator, unsliced conversion targets, paired small transforms
+        {"HYDIA_MODUP_PER_DIGIT": "1", "HYDIA_LOOPA_SEPARATE_IP": "1", "HYDIA_RELIN_SEPARATE_INTT": "1", "HYDIA_LOOPA_INT_IP": "1"},
     ]
     n = 40000
     rng = np.random.default_rng(77)
@@ -295,7 +298,8 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     results = []
     for env in variants:
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
-                  "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA"):
+                  "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA", "HYDIA_MODUP_PER_DIGIT",
+                  "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
