@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -133,6 +134,24 @@ DEV u64 p1_load(const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, 
     return v > (ql >> 1) ? negmod(reduce64(ql - v, M), M.q) : reduce64(v, M);
 }
 
+// pass 1's operand in the arithmetic's own representation.  Rescale spread (LD 2) into an FP64 limb needs no reduction at all: the
+// centred residue of the dropped 45-bit limb is an exact double well inside the transform's headroom, and the transform is linear
+template <class A, int LD>
+DEV typename A::T p1_load_as(const A &ar, const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, const u64 *s, int x, int slot,
+                             size_t idx, std::integral_constant<int, LD>) {
+    return ar.from_canon(p1_load<LD>(ld, mod, M, s, x, slot, idx));
+}
+DEV double p1_load_as(const FpA &ar, const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, const u64 *, int x, int, size_t idx,
+                      std::integral_constant<int, 2>) {
+    const u64 ql = mod[ld.l].q, v = ld.y[(size_t)x * ld.y_outer + idx];
+    if (ql >> 50) {  // a 60-bit dropped limb: reduce first
+        const u64 r = v > (ql >> 1) ? negmod(reduce64(ql - v, M), M.q) : reduce64(v, M);
+        return ar.from_canon(r);
+    }
+    const double dv = FpA::u2d(v);
+    return v > (ql >> 1) ? dv - FpA::u2d(ql) : dv;
+}
+
 // ------------------------------------------------------------------------------------------------ pass 1 (strided)
 template <class A, bool INV, int LD>
 DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u64 *d, u64 *lds, const ulonglong2 *ltw, int t,
@@ -143,8 +162,8 @@ DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u6
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            v[k] = ar.from_canon(p1_load<LD>(ld, mod, M, LD == 0 ? s : nullptr, x, slot,
-                                             (size_t)(g + 8 * k) * 256 + (LD == 0 ? 0 : c0) + col));
+            v[k] = p1_load_as(ar, ld, mod, M, LD == 0 ? s : nullptr, x, slot, (size_t)(g + 8 * k) * 256 + (LD == 0 ? 0 : c0) + col,
+                              std::integral_constant<int, LD>());
 #pragma unroll
         for (int st = 0; st < 4; st++) {
             const int h = 8 >> st;
