@@ -344,6 +344,10 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     tabs.fp_mask = 0;
     for (int m = 0; m < nT; m++)
         if (tabs.twf != nullptr && mod[m].ks + 2 <= 47) tabs.fp_mask |= 1u << m;
+    tabs.pm_mask = 0;  // OpenFHE's 60-bit primes sit just below 2^60 (q_0 = 2^60 - 0x3ffff, ...): HYDIA_NTT_INT / HYDIA_NTT_NO_PM keep Harvey [0, 4q)
+    if (!getenv("HYDIA_NTT_INT") && !getenv("HYDIA_NTT_NO_PM"))
+        for (int m = 0; m < nT; m++)
+            if (!((tabs.fp_mask >> m) & 1u) && mod[m].q < (1ull << 60) && (1ull << 60) - mod[m].q < (1ull << 24)) tabs.pm_mask |= 1u << m;
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
     fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;

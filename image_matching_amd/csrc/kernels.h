@@ -21,6 +21,7 @@ struct NttTables {
     const ulonglong2 *twf, *itwf;  // bit patterns of double pairs (w, w / q) for the FP64 path of the <= 47-bit primes
     const double *twd, *itwd;      // [nT][N] the twiddles alone as doubles (8 bytes each): the one-pass kernel's per-lane twiddle loads
     unsigned fp_mask;              // host copy of the kernels' own rule: bit m set <=> modulus m takes the FP64 path
+    unsigned pm_mask;              // bit m set <=> modulus m = 2^60 - c with c < 2^24 takes the lazy pseudo-Mersenne integer path (IntP)
 };
 
 // base conversion table: out[t] = sum_s y[s] * f[s][t] mod q_{dst t}

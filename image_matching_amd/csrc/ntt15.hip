@@ -50,8 +50,53 @@ struct IntA {
     }
     DEV void recentre(T &) const {}
     DEV void recentre_wide(T &) const {}
+    DEV void mid(T &) const {}
+    DEV T from_raw(u64 x) const { return x; }
     DEV u64 fin_fwd(T x) const {
         x = x >= q2 ? x - q2 : x;
+        return x >= q ? x - q : x;
+    }
+    DEV u64 fin_inv(T x, u64 sc, u64 scs) const { return mulmod_shoup(x, sc, scs, q); }
+};
+
+// q = 2^60 - c with c < 2^24 (every 60-bit prime OpenFHE picks for this parameter set): values live lazily in [0, 16q) = [0, 2^64 - 16c)
+// and a conditional subtraction (five instructions per butterfly) becomes an occasional three-instruction fold x -> (x mod 2^60) +
+// (x >> 60) c, which lands any 64-bit x in [0, 2^60 + 15c] inside [0, 2q).  Forward (Cooley-Tukey): a Shoup product of ANY b < 2^64 is in
+// [0, 2q), a' = a + t and b' = a - t + 2q grow the bound by 2q per stage: q -> 15q over pass 1's seven stages, fold on reading pass 1's
+// output, 2q -> 8q -> 14q over phases A and B, fold, 6q after phase C, fold + one subtraction to the canonical residue.  Inverse
+// (Gentleman-Sande): sums double, d = a - b + 8q needs b < 8q, so at most three stages run between folds (the hooks the FP64 path
+// re-centres at, plus one inside pass 1's four-stage group).  Same residues as IntA after the final reduction.
+struct IntP {
+    typedef u64 T;
+    typedef ulonglong2 TW;
+    u64 q, q2, q8;
+    unsigned c;
+    DEV IntP(const ModC &M) : q(M.q), q2(2 * M.q), q8(8 * M.q), c((unsigned)((1ull << 60) - M.q)) {}
+    DEV static TW tw(const ulonglong2 b) { return b; }
+    DEV T from_canon(u64 x) const { return x; }
+    DEV static T from_bits(u64 x) { return x; }
+    DEV static u64 to_bits(T x) { return x; }
+    DEV u64 fold(u64 x) const { return (x & ((1ull << 60) - 1)) + (u64)(unsigned)(x >> 60) * c; }
+    DEV void ct(T &a, T &b, const TW W) const {
+        const u64 hi = __umul64hi(b, W.y);
+        const u64 t = b * W.x - hi * q;
+        const u64 u = a;
+        a = u + t;
+        b = u - t + q2;
+    }
+    DEV void gs(T &a, T &b, const TW W) const {
+        const u64 s = a + b;
+        const u64 d = a - b + q8;
+        const u64 hi = __umul64hi(d, W.y);
+        b = d * W.x - hi * q;
+        a = s;
+    }
+    DEV void recentre(T &x) const { x = fold(x); }
+    DEV void recentre_wide(T &x) const { x = fold(x); }
+    DEV void mid(T &x) const { x = fold(x); }
+    DEV T from_raw(u64 x) const { return fold(x); }
+    DEV u64 fin_fwd(T x) const {
+        x = fold(x);
         return x >= q ? x - q : x;
     }
     DEV u64 fin_inv(T x, u64 sc, u64 scs) const { return mulmod_shoup(x, sc, scs, q); }
@@ -103,6 +148,8 @@ struct FpA {
     DEV void recentre_wide(T &x) const {
         if (!lean) recentre(x);
     }
+    DEV void mid(T &) const {}
+    DEV T from_raw(u64 x) const { return from_bits(x); }
     DEV u64 fin_fwd(T x) const {
         recentre(x);
         if (x < 0) x += q;
@@ -226,6 +273,10 @@ DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u6
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (!(k & h)) ar.gs(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
+            if (st == 2) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) ar.mid(v[k]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) d[(size_t)(g + 8 * k) * 256 + col] = ar.fin_inv(v[k], sc, scs);
@@ -249,6 +300,7 @@ __global__ __launch_bounds__(256) void k_ntt15_p1(NttTables T, const u64 *__rest
     const int t = threadIdx.x;
     if (t < 128) ltw[t] = tw[t];
     if (fp) p1_body<FpA, INV, LD>(FpA(M), tw, s, d, lds, ltw, t, scale.s[slot], scale.s_sh[slot], ld, T.mod, M, x, slot, c0);
+    else if ((T.pm_mask >> m) & 1u) p1_body<IntP, INV, LD>(IntP(M), tw, s, d, lds, ltw, t, scale.s[slot], scale.s_sh[slot], ld, T.mod, M, x, slot, c0);
     else p1_body<IntA, INV, LD>(IntA(M), tw, s, d, lds, ltw, t, scale.s[slot], scale.s_sh[slot], ld, T.mod, M, x, slot, c0);
 }
 
@@ -357,6 +409,9 @@ DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p,
 DEV void loop_a_inner_product(const LoopAIp &la, const IntA &, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
 }
+DEV void loop_a_inner_product(const LoopAIp &la, const IntP &, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
+}
 DEV void loop_a_inner_product(const LoopAIp &la, const FpA &ar, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     if (la.fp) loop_a_inner_product_fp(la, ar, x, p, j, idx, o0, o1);
     else loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
@@ -373,6 +428,15 @@ struct IpAcc<IntA> {
     DEV static V canon(u64 v) { return v; }
     DEV void mac(const IntA &, V v, u64 key) { s += (u128)v * key; }
     DEV u64 fin(const IntA &, const ModC &M, int terms) const { return reduce_lazy(s, M, terms); }
+};
+template <>
+struct IpAcc<IntP> {
+    typedef u64 V;
+    u128 s = 0;
+    DEV static V prep(const IntP &ar, u64 c) { return ar.fin_fwd(c); }
+    DEV static V canon(u64 v) { return v; }
+    DEV void mac(const IntP &, V v, u64 key) { s += (u128)v * key; }
+    DEV u64 fin(const IntP &, const ModC &M, int terms) const { return reduce_lazy(s, M, terms); }
 };
 template <>
 struct IpAcc<FpA> {
@@ -576,7 +640,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
         for (int p = 0; p < NP; p++)
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(s[p][blk * 256 + 32 * k + w]);  // raw from pass 1
+            for (int k = 0; k < 8; k++) v[p][k] = ar.from_raw(s[p][blk * 256 + 32 * k + w]);  // raw from pass 1
         {
             const TW W7 = A::tw(tw[128 + bg]);
             const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
@@ -651,6 +715,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             for (int p = 0; p < NP; p++) {
                 T c0 = A::from_bits(lds[p][la]), c1 = A::from_bits(lds[p][la + 1]), c2 = A::from_bits(lds[p][la + 2]),
                   c3 = A::from_bits(lds[p][la + 3]);
+                ar.mid(c0); ar.mid(c1); ar.mid(c2); ar.mid(c3);
                 ar.ct(c0, c2, W13);
                 ar.ct(c1, c3, W13);
                 ar.ct(c0, c1, W14a);
@@ -768,6 +833,7 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
         d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;
     }
     if (fp) p2_body<FpA, INV, NP, ST>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
     else p2_body<IntA, INV, NP, ST>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
 }
 
@@ -799,10 +865,12 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__r
         for (int pp = 0; pp < 2; pp++)
             dinv[pp] = stp.ip.inv_out + (size_t)(2 * x + pp) * stp.ip.inv_outer + (size_t)(stp.ip.inv_row0 + t - stp.ip.nl) * N + B0;
         if (fp) p2_body<FpA, false, NP, 6>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 6>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
         else p2_body<IntA, false, NP, 6>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
         return;
     }
     if (fp) p2_body<FpA, false, NP, 4>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 4>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
     else p2_body<IntA, false, NP, 4>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
 }
 
