@@ -425,8 +425,9 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
     const LimbSel qsel_full = sel_q(nl);
     std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
     const ScaleSel pinv_sel = scale_of(qsel_full, pinv, false);
-    hk::moddown_last_limb(stream, d_mod, N, acc, nE, c.d, c.ct_elems(), c.poly_elems(), acc + (size_t)l * N, (size_t)nE * N, XP, l,
-                          pinv_sel.s[l], pinv_sel.s_sh[l], dbl ? 1 : 0);
+    if (!fused_tail)
+        hk::moddown_last_limb(stream, d_mod, N, acc, nE, c.d, c.ct_elems(), c.poly_elems(), acc + (size_t)l * N, (size_t)nE * N, XP, l,
+                              pinv_sel.s[l], pinv_sel.s_sh[l], dbl ? 1 : 0);
     LimbSel tail{};
     tail.n = 1 + nP;
     tail.mod[0] = l;
@@ -436,7 +437,8 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
         tail_scale[1 + k] = Phat_inv[k];
     }
     if (fused_tail) {
-        hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, sel_range(l, l + 1));
+        hk::ntt15_inverse_p2_last_limb(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
+                                       c.d, c.ct_elems(), c.poly_elems(), dbl ? 1 : 0);
         hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
     } else {
         ntt_inv(acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail, scale_of(tail, tail_scale, true));

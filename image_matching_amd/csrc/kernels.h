@@ -230,6 +230,8 @@ void key_pack(hipStream_t st, const ModC *mod, int N, int nQ, int nT, int nd, co
 // the two halves of ntt15_inverse on their own (the fused key-switching tail runs the first pass of some rows elsewhere)
 void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X, const LimbSel &sel);
 void ntt15_inverse_p1(hipStream_t st, const NttTables &T, u64 *dst, size_t dst_outer, int X, const LimbSel &sel, const ScaleSel &scale);
+void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *acc_l, u64 *dst, size_t src_outer, size_t dst_outer, int XP, int l,
+                                u64 pinv, u64 pinv_sh, const u64 *addend, size_t add_x, size_t add_p, int dbl);
 // second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every
 // extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2).
 // inv_out != nullptr: the special-prime rows skip acc (see IpArgs)

@@ -794,6 +794,20 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 ulonglong2 i0, i1;
                 if (ST == 5) {  // the transform's input is loop A's inner product for these four coefficients
                     loop_a_inner_product(stp.la, ar, M, (xp0 + p) >> 1, (xp0 + p) & 1, slot, (unsigned)(B0 + e), i0, i1);
+                } else if (ST == 7) {  // ... is the dropped limb of the would-be ModDown output: (acc P^{-1} + addend)(x2), formed here
+                    const int xq = xp0 + p;
+                    const u64 *pa = stp.addend + (size_t)(xq >> 1) * stp.add_x + (size_t)(xq & 1) * stp.add_p + (size_t)stp.nl * 32768 + (B0 + e);
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(s[p] + e), a1 = *reinterpret_cast<const ulonglong2 *>(s[p] + e + 2);
+                    const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(pa), d1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
+                    const u64 qq = M.q, pv = stp.mul.s[slot], pvs = stp.mul.s_sh[slot];
+                    i0.x = addmod(mulmod_shoup(a0.x, pv, pvs, qq), d0.x, qq);
+                    i0.y = addmod(mulmod_shoup(a0.y, pv, pvs, qq), d0.y, qq);
+                    i1.x = addmod(mulmod_shoup(a1.x, pv, pvs, qq), d1.x, qq);
+                    i1.y = addmod(mulmod_shoup(a1.y, pv, pvs, qq), d1.y, qq);
+                    if (stp.dbl) {
+                        i0.x = addmod(i0.x, i0.x, qq); i0.y = addmod(i0.y, i0.y, qq);
+                        i1.x = addmod(i1.x, i1.x, qq); i1.y = addmod(i1.y, i1.y, qq);
+                    }
                 } else {
                     i0 = *reinterpret_cast<const ulonglong2 *>(s[p] + e);
                     i1 = *reinterpret_cast<const ulonglong2 *>(s[p] + e + 2);
@@ -839,16 +853,16 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
 
 // second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
 // workgroups that share a key tile follow each other.  Limb t = t0 + slot; the NP digits are all digits but the limb's own.
-template <int NP, bool OWN, bool TAIL = false>
-__global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
+template <int NP, bool OWN, bool TAIL>
+DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, const NttStore &stp, int y, int bx,
+                         u64 (*lds)[8 * 288]) {
     constexpr int N = 32768;
-    __shared__ u64 lds[(TAIL && NP < 2) ? 2 : NP][8 * 288];
-    const int y = blockIdx.y, slot = y / X, x = y - slot * X, t = t0 + slot;
+    const int slot = y / X, x = y - slot * X, t = t0 + slot;
     const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
     const ModC M = T.mod[m];
     const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
     const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
-    const int B0 = blockIdx.x * 2048;
+    const int B0 = bx * 2048;
     const int own_d = OWN ? t / stp.ip.alpha : (1 << 30);
     const u64 *s[NP];
     u64 *d[NP];
@@ -872,6 +886,20 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__r
     if (fp) p2_body<FpA, false, NP, 4>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
     else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 4>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
     else p2_body<IntA, false, NP, 4>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+}
+template <int NP, bool OWN, bool TAIL = false>
+__global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
+    __shared__ u64 lds[(TAIL && NP < 2) ? 2 : NP][8 * 288];
+    p2_ip_workgroup<NP, OWN, TAIL>(T, dig, dxs, X, t0, stp, blockIdx.y, blockIdx.x, lds);
+}
+// both halves of a relinearisation's fused inner product in ONE launch: workgroups y < nl X take the Q limbs (ND - 1 digits transformed,
+// the limb's own digit read in place), the rest the special-prime limbs with the inverse tail (ND digits)
+template <int ND>
+__global__ __launch_bounds__(256) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, NttStore stp) {
+    __shared__ u64 lds[ND][8 * 288];
+    const int yq = stp.ip.nl * X;
+    if ((int)blockIdx.y < yq) p2_ip_workgroup<ND - 1, true, false>(T, dig, dxs, X, 0, stp, blockIdx.y, blockIdx.x, lds);
+    else p2_ip_workgroup<ND, false, true>(T, dig, dxs, X, stp.ip.nl, stp, blockIdx.y - yq, blockIdx.x, lds);
 }
 
 
@@ -1176,16 +1204,25 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     stp.ip.inv_out = inv_out;
     stp.ip.inv_outer = inv_outer;
     stp.ip.inv_row0 = inv_row0;
-    if (nd >= 2) {  // NP pass-1 digits in (+ the limb's own residues), two accumulator rows out; the key tiles are shared by all x (L2)
-        char name[64];
+    // Q limbs: NP = nd - 1 pass-1 digits in (+ the limb's own residues), two accumulator rows out; special-prime limbs: nd digits in, two
+    // rows out; the key tiles are shared by all x (L2)
+    const double bytes_q = nd >= 2 ? ((nd - 1) + 1 + 2.0) * nl * X * 262144.0 : 0.0, bytes_p = (nd + 2.0) * nP * X * 262144.0;
+    const bool merged = inv_out && nd >= 2 && nd <= 4 && !getenv("HYDIA_RELIN_TWO_IP_LAUNCHES");
+    char name[64];
+    if (merged) {
+        snprintf(name, sizeof name, "k_ntt15_p2_ip_all<%d>", nd);
+        ledger_add(name, bytes_q + bytes_p);
+        if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip_all<2>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, stp);
+        else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip_all<3>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, stp);
+        else hipLaunchKernelGGL((k_ntt15_p2_ip_all<4>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, stp);
+        return;
+    }
+    if (nd >= 2) {
         snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, true, false>", nd - 1 > 3 ? 3 : nd - 1);
-        ledger_add(name, ((nd - 1) + 1 + 2.0) * nl * X * 262144.0);
+        ledger_add(name, bytes_q);
     }
-    {
-        char name[64];
-        snprintf(name, sizeof name, inv_out ? "k_ntt15_p2_ip<%d, false, true>" : "k_ntt15_p2_ip<%d, false, false>", nd > 4 ? 4 : nd);
-        ledger_add(name, (nd + 2.0) * nP * X * 262144.0);
-    }
+    snprintf(name, sizeof name, inv_out ? "k_ntt15_p2_ip<%d, false, true>" : "k_ntt15_p2_ip<%d, false, false>", nd > 4 ? 4 : nd);
+    ledger_add(name, bytes_p);
     // Q limbs: nd - 1 digits are transformed, the limb's own digit is read from c2
     if (nd == 1) {
         LimbSel qs{};
@@ -1373,6 +1410,28 @@ void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *d
         hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, 0, sel.n, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, 0, sel.n, stp);
+}
+// first inverse pass of limb l of (acc P^{-1} + addend)(x2) — k_moddown_last_limb's arithmetic in the load (relin + rescale tail)
+void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *acc_l, u64 *dst, size_t so, size_t dso, int XP, int l,
+                                u64 pinv, u64 pinv_sh, const u64 *addend, size_t add_x, size_t add_p, int dbl) {
+    NttStore stp{};
+    stp.mode = 7;
+    stp.nl = l;
+    stp.mul.s[0] = pinv;
+    stp.mul.s_sh[0] = pinv_sh;
+    stp.addend = addend;
+    stp.add_x = add_x;
+    stp.add_p = add_p;
+    stp.dbl = dbl;
+    LimbSel sel{};
+    sel.n = 1;
+    sel.mod[0] = l;
+    const bool pair = pair_polys(XP, 1);
+    ledger_add(pair ? "k_ntt15_p2<true, 2, 7>" : "k_ntt15_p2<true, 1, 7>", 3.0 * XP * 262144.0);
+    if (pair)
+        hipLaunchKernelGGL((k_ntt15_p2<true, 2, 7>), dim3(16, XP / 2), dim3(256), 0, st, T, acc_l, dst, so, dso, sel, 0, 1, stp);
+    else
+        hipLaunchKernelGGL((k_ntt15_p2<true, 1, 7>), dim3(16, XP), dim3(256), 0, st, T, acc_l, dst, so, dso, sel, 0, 1, stp);
 }
 void ntt15_inverse_p1(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const ScaleSel &scale) {
     NttLoad ld{};

@@ -289,6 +289,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         # round-2 fusions switched off one group at a time: per-digit ModUp launches, loop A's special-prime inner product as its own
         # kernel, the relinearisation's special-prime rows through the accumulator, unsliced conversion targets, paired small transforms
         {"HYDIA_MODUP_PER_DIGIT": "1", "HYDIA_LOOPA_SEPARATE_IP": "1", "HYDIA_RELIN_SEPARATE_INTT": "1", "HYDIA_LOOPA_INT_IP": "1"},
+        {"HYDIA_NTT_NO_PM": "1", "HYDIA_RELIN_TWO_IP_LAUNCHES": "1"},  # Harvey [0, 4q) butterflies for the 60-bit primes; two inner-product launches
     ]
     n = 40000
     rng = np.random.default_rng(77)
@@ -299,7 +300,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     for env in variants:
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
                   "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA", "HYDIA_MODUP_PER_DIGIT",
-                  "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP"):
+                  "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP", "HYDIA_NTT_NO_PM", "HYDIA_RELIN_TWO_IP_LAUNCHES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
