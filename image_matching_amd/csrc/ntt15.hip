@@ -1262,9 +1262,9 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
 // alone +0.35 ms per query).  So it is OFF by default.  HYDIA_NTT_1PASS = every FP64 transform of at least HYDIA_NTT_1PASS_MIN
 // limb-polynomials (default 1024).  Read per call: the parity tests flip the switches inside one process.
 static bool use_one_pass(bool inv, int ld, int st, int items) {
-    (void)inv;
-    (void)st;
-    if (!getenv("HYDIA_NTT_1PASS") || ld == 1) return false;
+    const char *sw = getenv("HYDIA_NTT_1PASS");
+    if (!sw || ld == 1) return false;
+    if (sw[0] == 'p' && !(ld == 0 && st == 0)) return false;  // "plain": only transforms without a fused prologue / epilogue
     const char *e = getenv("HYDIA_NTT_1PASS_MIN");
     return items >= (e ? atoi(e) : 1024);
 }
