@@ -854,10 +854,9 @@ __global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__rest
 // second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
 // workgroups that share a key tile follow each other.  Limb t = t0 + slot; the NP digits are all digits but the limb's own.
 template <int NP, bool OWN, bool TAIL>
-DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, const NttStore &stp, int y, int bx,
+DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t dxs, int t, int x, const NttStore &stp, int bx,
                          u64 (*lds)[8 * 288]) {
     constexpr int N = 32768;
-    const int slot = y / X, x = y - slot * X, t = t0 + slot;
     const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
     const ModC M = T.mod[m];
     const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
@@ -890,16 +889,23 @@ DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t
 template <int NP, bool OWN, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
     __shared__ u64 lds[(TAIL && NP < 2) ? 2 : NP][8 * 288];
-    p2_ip_workgroup<NP, OWN, TAIL>(T, dig, dxs, X, t0, stp, blockIdx.y, blockIdx.x, lds);
+    const int slot = blockIdx.y / X, x = blockIdx.y - slot * X;  // x fastest: the workgroups that share a key tile follow each other
+    p2_ip_workgroup<NP, OWN, TAIL>(T, dig, dxs, t0 + slot, x, stp, blockIdx.x, lds);
 }
-// both halves of a relinearisation's fused inner product in ONE launch: workgroups y < nl X take the Q limbs (ND - 1 digits transformed,
-// the limb's own digit read in place), the rest the special-prime limbs with the inverse tail (ND digits)
+// both halves of a relinearisation's fused inner product in ONE launch: the Q limbs (ND - 1 digits transformed, the limb's own digit
+// read in place; FP64, HBM-bound) and the special-prime limbs with the inverse tail (ND digits; 60-bit integer, ALU-bound).  Rows of
+// workgroups are ordered so that the two kinds run side by side on every CU: groups of xb = 8 ciphertexts, inside a group the nP
+// special-prime rows spread evenly among the nl Q rows (Bresenham), inside a row x fastest (the 8 workgroups that share a key tile follow
+// each other; a tile is re-fetched once per group, from the Infinity Cache).
 template <int ND>
-__global__ __launch_bounds__(256) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, NttStore stp) {
+__global__ __launch_bounds__(256) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int xb, NttStore stp) {
     __shared__ u64 lds[ND][8 * 288];
-    const int yq = stp.ip.nl * X;
-    if ((int)blockIdx.y < yq) p2_ip_workgroup<ND - 1, true, false>(T, dig, dxs, X, 0, stp, blockIdx.y, blockIdx.x, lds);
-    else p2_ip_workgroup<ND, false, true>(T, dig, dxs, X, stp.ip.nl, stp, blockIdx.y - yq, blockIdx.x, lds);
+    const int nl = stp.ip.nl, nS = stp.ip.nE, nP = nS - nl;
+    const int per = nS * xb, grp = blockIdx.y / per, r = blockIdx.y - grp * per;
+    const int si = r / xb, x = grp * xb + (r - si * xb);
+    const int pc = si * nP / nS, pc1 = (si + 1) * nP / nS;
+    if (pc1 > pc) p2_ip_workgroup<ND, false, true>(T, dig, dxs, nl + pc, x, stp, blockIdx.x, lds);
+    else p2_ip_workgroup<ND - 1, true, false>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);
 }
 
 
@@ -1212,9 +1218,12 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     if (merged) {
         snprintf(name, sizeof name, "k_ntt15_p2_ip_all<%d>", nd);
         ledger_add(name, bytes_q + bytes_p);
-        if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip_all<2>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, stp);
-        else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip_all<3>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, stp);
-        else hipLaunchKernelGGL((k_ntt15_p2_ip_all<4>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, stp);
+        int xb = 8;  // ciphertexts per interleaving group (HYDIA_IP_GROUP; must divide X)
+        if (const char *e = getenv("HYDIA_IP_GROUP")) xb = atoi(e) > 0 ? atoi(e) : 8;
+        if (xb > X || X % xb) xb = X;
+        if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip_all<2>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
+        else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip_all<3>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
+        else hipLaunchKernelGGL((k_ntt15_p2_ip_all<4>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
         return;
     }
     if (nd >= 2) {
