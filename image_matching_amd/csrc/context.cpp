@@ -344,6 +344,19 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     tabs.fp_mask = 0;
     for (int m = 0; m < nT; m++)
         if (tabs.twf != nullptr && mod[m].ks + 2 <= 47) tabs.fp_mask |= 1u << m;
+    {
+        const char *sw = getenv("HYDIA_NTT_1PASS");
+        tabs.one_pass = !sw ? 0 : (sw[0] == 'p' ? 2 : 1);
+        const char *mn = getenv("HYDIA_NTT_1PASS_MIN");
+        tabs.one_pass_min = mn ? atoi(mn) : 1024;
+        tabs.two_ip_launches = getenv("HYDIA_RELIN_TWO_IP_LAUNCHES") ? 1 : 0;
+        const char *g = getenv("HYDIA_IP_GROUP");
+        tabs.ip_group = g && atoi(g) > 0 ? atoi(g) : 8;
+    }
+    modup_per_digit = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
+    loop_a_separate_ip = getenv("HYDIA_LOOPA_SEPARATE_IP") != nullptr;
+    loop_a_int_ip = getenv("HYDIA_LOOPA_INT_IP") != nullptr;
+    relin_separate_intt = getenv("HYDIA_RELIN_SEPARATE_INTT") != nullptr;
     tabs.pm_mask = 0;  // OpenFHE's 60-bit primes sit just below 2^60 (q_0 = 2^60 - 0x3ffff, ...): HYDIA_NTT_INT / HYDIA_NTT_NO_PM keep Harvey [0, 4q)
     if (!getenv("HYDIA_NTT_INT") && !getenv("HYDIA_NTT_NO_PM"))
         for (int m = 0; m < nT; m++)

@@ -80,7 +80,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
     ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
     const bool fused_conv = prm.logN == 15 && fuse_bconv;
     if (!fused_conv) hk::base_convert_digits(stream, d_mod, N, y, (size_t)nl * N, dig, dig_x, X, pl.d_tabs, nd, nl, nE, esel);
-    const bool no_merge = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
+    const bool no_merge = modup_per_digit;
     const bool merged = !fused_conv && !no_merge && nd > 1 && (size_t)X * nd * nE < 128;
     if (merged) {
         if (p1_only) hk::ntt15_forward_p1(stream, tabs, dig, dig, (size_t)nE * N, (size_t)nE * N, X * nd, esel);
@@ -155,7 +155,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
         {
             const int x0 = 0, Xc = X;
             u64 *y = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
-            const bool ip_in_intt = getenv("HYDIA_LOOPA_SEPARATE_IP") == nullptr;
+            const bool ip_in_intt = !loop_a_separate_ip;
             if (ip_in_intt) {
                 // the special-prime limbs of <digits, key> are formed in the load of the ModDown inverse transform (never in HBM)
                 LoopAIp lp{};
@@ -198,7 +198,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
             stp.la.nT = nT;
             stp.la.packed_nQ = keys_packed_nQ;
             stp.la.premul = premul ? 1 : 0;
-            stp.la.fp = getenv("HYDIA_LOOPA_INT_IP") ? 0 : 1;
+            stp.la.fp = loop_a_int_ip ? 0 : 1;
             hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
             pool.put(conv);
         }
@@ -409,7 +409,7 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
     u64 *yu = pool.get((size_t)XP * yu_outer * sizeof(u64));
     // with the fused inner product the special-prime sums never reach acc: the kernel runs the first pass of their inverse
     // transform itself and leaves its raw image in yu (HYDIA_RELIN_SEPARATE_INTT: through acc, as before)
-    const bool tail_in_ip = getenv("HYDIA_RELIN_SEPARATE_INTT") == nullptr;
+    const bool tail_in_ip = !relin_separate_intt;
     const bool fused_tail = fip && tail_in_ip && prm.logN == 15;
     timer_begin("ks_inner_product");
     if (fip)

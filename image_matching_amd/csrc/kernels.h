@@ -22,6 +22,11 @@ struct NttTables {
     const double *twd, *itwd;      // [nT][N] the twiddles alone as doubles (8 bytes each): the one-pass kernel's per-lane twiddle loads
     unsigned fp_mask;              // host copy of the kernels' own rule: bit m set <=> modulus m takes the FP64 path
     unsigned pm_mask;              // bit m set <=> modulus m = 2^60 - c with c < 2^24 takes the lazy pseudo-Mersenne integer path (IntP)
+    // launch-shape switches, read from the environment ONCE per context (host side only; the parity tests build one context per variant)
+    int one_pass;                  // HYDIA_NTT_1PASS: 0 off (default), 1 every FP64 transform, 2 ("plain") only transforms without fused prologue / epilogue
+    int one_pass_min;              // HYDIA_NTT_1PASS_MIN: smallest launch (limb-polynomials) that takes the one-pass kernel (default 1024)
+    int two_ip_launches;           // HYDIA_RELIN_TWO_IP_LAUNCHES: Q and special-prime halves of the fused inner product as two launches
+    int ip_group;                  // HYDIA_IP_GROUP: ciphertexts per interleaving group of the merged inner-product kernel (default 8)
 };
 
 // base conversion table: out[t] = sum_s y[s] * f[s][t] mod q_{dst t}

@@ -1213,14 +1213,13 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     // Q limbs: NP = nd - 1 pass-1 digits in (+ the limb's own residues), two accumulator rows out; special-prime limbs: nd digits in, two
     // rows out; the key tiles are shared by all x (L2)
     const double bytes_q = nd >= 2 ? ((nd - 1) + 1 + 2.0) * nl * X * 262144.0 : 0.0, bytes_p = (nd + 2.0) * nP * X * 262144.0;
-    const bool merged = inv_out && nd >= 2 && nd <= 4 && !getenv("HYDIA_RELIN_TWO_IP_LAUNCHES");
+    const bool merged = inv_out && nd >= 2 && nd <= 4 && !T.two_ip_launches;
     char name[64];
     if (merged) {
         snprintf(name, sizeof name, "k_ntt15_p2_ip_all<%d>", nd);
         ledger_add(name, bytes_q + bytes_p);
-        int xb = 8;  // ciphertexts per interleaving group (HYDIA_IP_GROUP; must divide X)
-        if (const char *e = getenv("HYDIA_IP_GROUP")) xb = atoi(e) > 0 ? atoi(e) : 8;
-        if (xb > X || X % xb) xb = X;
+        int xb = T.ip_group;  // ciphertexts per interleaving group (HYDIA_IP_GROUP; must divide X)
+        if (xb < 1 || xb > X || X % xb) xb = X;
         if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip_all<2>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
         else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip_all<3>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
         else hipLaunchKernelGGL((k_ntt15_p2_ip_all<4>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
@@ -1262,20 +1261,19 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
 // ---- launch plumbing.  With the one-pass kernel enabled (HYDIA_NTT_1PASS) a LimbSel is cut into maximal runs of slots whose moduli
 // take the same arithmetic path: FP64 runs go to the one-pass kernel (not for the fused first-pass base conversion, which it does
 // not implement), integer runs — the 60-bit q_0 and the special primes — to the two-pass kernels restricted to that slot range.
-// read per call: tests flip it inside one process.  HYDIA_NTT_1PASS_MIN = smallest number of limb-polynomials in a launch for which
+// The switches are read once per context (NttTables::one_pass*).  HYDIA_NTT_1PASS_MIN = smallest number of limb-polynomials in a launch for which
 // the one-pass kernel is used: it needs one whole workgroup of 1024 threads per limb-polynomial, so small batches (the per-query
 // fixed-cost work) fill the GPU better with the two-pass kernels' 24 smaller workgroups per limb-polynomial
 // Measured on MI355X (profiles/r02/ntt_one_pass.md): the one-pass kernel is 1.15x faster than the two passes on plain transforms
 // streamed from HBM in launches of thousands of limb-polynomials, slower on small or Infinity-Cache-resident batches and on the
 // fused epilogues; inside a query it loses everywhere it was tried (whole pipeline +1.2 ms at 2^20; loop A's ModDown transforms
 // alone +0.35 ms per query).  So it is OFF by default.  HYDIA_NTT_1PASS = every FP64 transform of at least HYDIA_NTT_1PASS_MIN
-// limb-polynomials (default 1024).  Read per call: the parity tests flip the switches inside one process.
-static bool use_one_pass(bool inv, int ld, int st, int items) {
-    const char *sw = getenv("HYDIA_NTT_1PASS");
-    if (!sw || ld == 1) return false;
-    if (sw[0] == 'p' && !(ld == 0 && st == 0)) return false;  // "plain": only transforms without a fused prologue / epilogue
-    const char *e = getenv("HYDIA_NTT_1PASS_MIN");
-    return items >= (e ? atoi(e) : 1024);
+// limb-polynomials (default 1024); HYDIA_NTT_1PASS=plain restricts it to transforms without fused prologue / epilogue.
+static bool use_one_pass(const NttTables &T, bool inv, int ld, int st, int items) {
+    (void)inv;
+    if (!T.one_pass || ld == 1) return false;
+    if (T.one_pass == 2 && !(ld == 0 && st == 0)) return false;  // "plain": only transforms without a fused prologue / epilogue
+    return items >= T.one_pass_min;
 }
 template <class F>
 static void for_slot_runs(const NttTables &T, const LimbSel &sel, bool split, F fn) {
@@ -1345,9 +1343,9 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
 template <int LD, int ST>
 static void forward_runs(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel,
                          const NttLoad &ld, const NttStore &stp) {
-    const bool split = T.fp_mask != 0 && use_one_pass(false, LD, ST, X * sel.n);
+    const bool split = T.fp_mask != 0 && use_one_pass(T, false, LD, ST, X * sel.n);
     for_slot_runs(T, sel, split, [&](int s0, int n, bool fp) {
-        if (fp && split && use_one_pass(false, LD, ST, X * n)) {
+        if (fp && split && use_one_pass(T, false, LD, ST, X * n)) {
             ScaleSel dummy = {};
             launch_1p<false, LD, ST>(st, T, src, dst, so, dso, X, sel, s0, n, dummy, ld, stp);
         } else {
@@ -1451,9 +1449,9 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
                    const LimbSel &sel, const ScaleSel &scale) {
     NttLoad ld{};
     NttStore stp{};
-    const bool split = T.fp_mask != 0 && use_one_pass(true, 0, 0, X * sel.n);
+    const bool split = T.fp_mask != 0 && use_one_pass(T, true, 0, 0, X * sel.n);
     for_slot_runs(T, sel, split, [&](int s0, int n, bool fp) {
-        if (fp && split && use_one_pass(true, 0, 0, X * n)) {
+        if (fp && split && use_one_pass(T, true, 0, 0, X * n)) {
             launch_1p<true, 0, 0>(st, T, src, dst, so, dso, X, sel, s0, n, scale, ld, stp);
             return;
         }
