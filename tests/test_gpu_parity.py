@@ -289,7 +289,9 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         # round-2 fusions switched off one group at a time: per-digit ModUp launches, loop A's special-prime inner product as its own
         # kernel, the relinearisation's special-prime rows through the accumulator, unsliced conversion targets, paired small transforms
         {"HYDIA_MODUP_PER_DIGIT": "1", "HYDIA_LOOPA_SEPARATE_IP": "1", "HYDIA_RELIN_SEPARATE_INTT": "1", "HYDIA_LOOPA_INT_IP": "1"},
-        {"HYDIA_NTT_NO_PM": "1", "HYDIA_RELIN_TWO_IP_LAUNCHES": "1"},  # Harvey [0, 4q) butterflies for the 60-bit primes; two inner-product launches
+        {"HYDIA_NTT_NO_PM": "1", "HYDIA_RELIN_TWO_IP_LAUNCHES": "1"},
+        # the unfused pipeline on the default arithmetics (FP64 + lazy pseudo-Mersenne butterflies through the plain epilogues)
+        {"HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_KEYS_UNPACKED": "1"},  # Harvey [0, 4q) butterflies for the 60-bit primes; two inner-product launches
     ]
     n = 40000
     rng = np.random.default_rng(77)
