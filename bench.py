@@ -239,6 +239,14 @@ def main():
             sim = sender.computeSimilarity(qc)
         cc.sync()
         ms_similarity = (time.time() - t1) / 3 * 1e3
+        # membershipScenario (sender_diag.cpp:35-50) = indexScenario + EvalAddMany + EvalSum: the other published column
+        t1 = time.time()
+        for _ in range(3):
+            mem = sender.membershipScenario(qc)
+        cc.sync()
+        ms_membership = (time.time() - t1) / 3 * 1e3
+        membership_ok = None if args.random_db else bool(receiver.decryptMembership(mem))
+        del mem
         del sim
     # correctness of what was just timed: rank 0 holds every block's result in global block order -> global indices
     correct = True
@@ -307,7 +315,9 @@ def main():
         }
         if ms_similarity is not None:
             out["config"]["secondary"] = {"computeSimilarity_ms_per_query": round(ms_similarity, 3),
-                                          "computeSimilarity_vectors_per_s": round(n_local / ms_similarity * 1e3)}
+                                          "computeSimilarity_vectors_per_s": round(n_local / ms_similarity * 1e3),
+                                          "membershipScenario_ms_per_query": round(ms_membership, 3),
+                                          "membershipScenario_result": membership_ok}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
