@@ -152,6 +152,10 @@ class DistDiagonalSender:
         b = self._bufs.get(key)
         if b is None or b.numel() != n:
             b = self.torch.zeros(n, dtype=self.torch.int64, device="cuda" if self.staging == "device" else "cpu")
+            if self.staging == "device":
+                # the zero fill runs on torch's stream, which may still be waiting for an earlier collective; the library writes
+                # into the buffer from its OWN stream right after this — without the wait the fill can land on top of the data
+                self.torch.cuda.current_stream().synchronize()
             self._bufs[key] = b
         return b
 

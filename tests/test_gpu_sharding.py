@@ -167,6 +167,140 @@ def test_dist_sender_two_ranks_on_one_gpu(im, tmp_path):
         assert np.array_equal(got[k], want[k]), k
 
 
+THREAD_DIST_SCRIPT = r'''
+import os, sys, threading
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import torch
+import image_matching_amd as im
+from test_gpu_sharding import make_db, single_context_results
+
+
+class ThreadDist:
+    """torch.distributed stand-in for R ranks that are THREADS of this process sharing GPU 0, with NCCL's stream semantics: a collective
+    is enqueued on the rank's own communication stream, which first waits for the rank's current stream; the call returns at once and
+    the rank's current stream is made to wait for the collective (what Work.wait() does) — nothing blocks the host.  So the class under
+    test must order its own stream, torch's stream and the collectives itself, exactly as under RCCL (which refuses two ranks on one
+    GPU, so the real backend cannot run the world > 1 device-staging path on a one-GPU box)."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world):
+        import threading
+        import torch
+        self.torch, self.world = torch, world
+        self.bar = threading.Barrier(world)
+        self.local = threading.local()
+        self.slots = [None] * world
+        self.comm = [torch.cuda.Stream() for _ in range(world)]
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def _run(self, fn):
+        """publish -> everybody's operand is visible -> enqueue on the comm stream -> the others may move on"""
+        torch, r = self.torch, self.local.rank
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.slots[r] = dict(self.slots[r], ready=ready)
+        self.bar.wait()
+        with torch.cuda.stream(self.comm[r]):
+            for other in self.slots:
+                self.comm[r].wait_event(other["ready"])   # the peers' operands are produced on THEIR current streams
+            torch.cuda._sleep(50_000_000)                 # the collective completes LATE (~20 ms, longer than a local query): a consumer that does not wait reads stale data
+            fn(r)
+        cur.wait_stream(self.comm[r])
+        done = torch.cuda.Event()
+        done.record(self.comm[r])
+        self.slots[r]["done"] = done
+        self.bar.wait()
+        for other in self.slots:                           # a peer must not overwrite its operand before every reader is through
+            cur.wait_event(other["done"])
+        self.bar.wait()
+
+    def broadcast(self, t, src):
+        self.slots[self.local.rank] = dict(t=t)
+        self._run(lambda r: t.copy_(self.slots[src]["t"], non_blocking=True) if r != src else None)
+
+    def gather(self, t, recv, dst):
+        self.slots[self.local.rank] = dict(t=t)
+        self._run(lambda r: [recv[k].copy_(self.slots[k]["t"], non_blocking=True) for k in range(self.world)] if r == dst else None)
+
+    def reduce(self, t, dst, op):
+        assert op == self.ReduceOp.SUM
+        self.slots[self.local.rank] = dict(t=t)
+        self._run(lambda r: [t.add_(self.slots[k]["t"]) for k in range(self.world) if k != dst] if r == dst else None)
+
+    def broadcast_object_list(self, objs, src):
+        r = self.local.rank
+        if r == src:
+            self.obj = list(objs)
+        self.bar.wait()
+        objs[:] = self.obj
+        self.bar.wait()
+
+
+n, world = 5000, 3
+prm = im.default_params(log_n=11, vector_dim=64)
+planted = [0, 1024, n - 1]
+db = make_db(n, 64, planted, n)
+want = single_context_results(im, prm, n, db, planted, np.ones(64))
+td = ThreadDist(world)
+got, errors = {}, []
+
+
+def rank_main(rank):
+    try:
+        td.bind(rank)
+        with torch.cuda.stream(torch.cuda.Stream()):     # every rank has its own "current" stream, like separate processes
+            cc = im.Context(prm, 0)
+            cc.keygen(31)
+            enr = im.DistDiagonalEnroller(cc, n, rank, world)
+            enr.serializeDB(np.ascontiguousarray(db[enr.first:enr.last]), seed=8)
+            sender = im.DistDiagonalSender(cc, n, td, rank, world, staging="device")
+            receiver = im.DiagonalReceiver(cc, n)
+            for rep in range(2):
+                q = receiver.encryptQuery(np.ones(64), seed=2, nonce=9) if rank == 0 else None
+                sim, idx, mem = sender.computeSimilarity(q), sender.indexScenario(q), sender.membershipScenario(q)
+                if rank == 0:
+                    got[rep] = dict(sim=sim.export(), idx=idx.export(), mem=mem.export(), found=receiver.decryptIndex(idx),
+                                    member=receiver.decryptMembership(mem))
+                del q, sim, idx, mem
+            td.bar.wait()
+            cc.close()
+    except Exception as e:  # noqa: BLE001
+        errors.append((rank, repr(e)))
+        td.bar.abort()
+
+
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join(timeout=600)
+assert not errors, errors
+for rep in range(2):
+    for k in ("sim", "idx", "mem"):
+        assert np.array_equal(got[rep][k], want[k]), (rep, k)
+    assert got[rep]["found"] == want["found"] and got[rep]["member"] is True
+print("thread-dist ok")
+'''
+
+
+def test_dist_sender_device_staging_under_async_collectives(tmp_path):
+    """DistDiagonalSender with staging="device" and world = 3 (uneven shards: 2 + 2 + 1 blocks of 1024 vectors): three threads, three
+    contexts on GPU 0, collectives with NCCL's asynchronous stream semantics (ThreadDist in the script above: RCCL itself refuses two
+    ranks on one GPU) that complete a few milliseconds LATE.  Rank 0's gathered similarity / index batches and its reduced membership
+    ciphertext equal the single-context ones bit for bit, twice in a row (buffer reuse).  Runs in its own process (torch's HIP runtime
+    next to the library's, started before anything forks)."""
+    script = tmp_path / "thread_dist.py"
+    script.write_text(THREAD_DIST_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "thread-dist ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_rekey_refreshes_loop_a_keys(im):
     """keygen(a), query, keygen(b) on the SAME context, query: must equal a fresh context keyed with b (loop A streams a packed
     shadow of the rotation keys that has to follow every re-key — round-1 advisor finding)."""
