@@ -242,9 +242,9 @@ class ThreadDist:
         self.bar.wait()
 
 
-n, world = 5000, 3
+n, world = int(sys.argv[2]), 3
 prm = im.default_params(log_n=11, vector_dim=64)
-planted = [0, 1024, n - 1]
+planted = sorted({0, min(1024, n - 1), n - 1})
 db = make_db(n, 64, planted, n)
 want = single_context_results(im, prm, n, db, planted, np.ones(64))
 td = ThreadDist(world)
@@ -289,15 +289,17 @@ print("thread-dist ok")
 '''
 
 
-def test_dist_sender_device_staging_under_async_collectives(tmp_path):
-    """DistDiagonalSender with staging="device" and world = 3 (uneven shards: 2 + 2 + 1 blocks of 1024 vectors): three threads, three
+@pytest.mark.parametrize("n", [5000, 1000])
+def test_dist_sender_device_staging_under_async_collectives(tmp_path, n):
+    """DistDiagonalSender with staging="device" and world = 3 (n = 5000: uneven shards of 2 + 2 + 1 blocks of 1024 vectors; n = 1000: one
+    block, ranks 1 and 2 own nothing): three threads, three
     contexts on GPU 0, collectives with NCCL's asynchronous stream semantics (ThreadDist in the script above: RCCL itself refuses two
     ranks on one GPU) that complete a few milliseconds LATE.  Rank 0's gathered similarity / index batches and its reduced membership
     ciphertext equal the single-context ones bit for bit, twice in a row (buffer reuse).  Runs in its own process (torch's HIP runtime
     next to the library's, started before anything forks)."""
     script = tmp_path / "thread_dist.py"
     script.write_text(THREAD_DIST_SCRIPT)
-    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(n)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "thread-dist ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
