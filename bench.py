@@ -150,6 +150,12 @@ def main():
     ap.add_argument("--random-db", action="store_true", help="fill the DB with random residues instead of enrolling")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON result.  Native libraries write there too (RCCL prints a five-line version banner on fd 1 when
+    # its first communicator comes up), so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -320,7 +326,8 @@ def main():
                                           "membershipScenario_result": membership_ok}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
