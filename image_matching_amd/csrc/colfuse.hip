@@ -1,0 +1,307 @@
+// image_matching_amd/csrc/colfuse.hip — column-fused base conversion of hybrid key switching for N = 2^15 on gfx950:
+// inverse pass 1' of the sources, fast base conversion, forward pass 1 of the targets in ONE kernel (no HBM round trip in between).
+// Replaces, bit for bit, k_ntt15_p1<true> + k_base_convert / k_base_convert_digits / k_moddown_rescale_conv + k_ntt15_p1<false> of
+// every ModUp and ModDown: the hoisted rotations of DiagonalSender::computeSimilarity (/root/reference/src/sender/sender_diag.cpp:22-26),
+// RelinearizeInPlace + RescaleInPlace (:79-80) and the ct x ct products of chebyshevCompare (src/openFHE_wrapper.cpp:143-185).
+#include <algorithm>
+
+#include "kernels.h"
+#include "ntt_arith.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ column-fused conversion
+// Every base conversion of hybrid key switching sits between two transforms: the sources leave the evaluation domain (inverse pass 2',
+// then pass 1'), are converted coefficient by coefficient, and the targets enter it again (pass 1, then pass 2).  Pass 1', the
+// conversion and pass 1 all act on COLUMNS of the 128 x 256 coefficient matrix, so the workgroup that owns 32 adjacent columns runs
+// all three back to back: the sources' coefficient-form values stay in registers (16 rows x <= 4 sources per lane), each target is
+// converted straight into the forward butterflies' operands, and neither the coefficient-form sources nor the converted rows ever
+// exist in HBM (loop A: 8 of its 29 GiB; every ModUp / ModDown of the comparator: two round trips per row and two launches).
+// Same butterflies, same conversion sums, same final reductions as k_ntt15_p1<true> + k_base_convert[_digits] /
+// k_moddown_rescale_conv + k_ntt15_p1<false>: bit-identical (HYDIA_NO_COLFUSE runs those instead).
+// LDS: two 32 KiB exchange images used alternately (ONE barrier per tile transform), the sources' phase-B twiddles, two alternating
+// sets for the targets.  256 registers per lane -> two workgroups per CU; every global load of a workgroup is issued up front.
+constexpr int CF_LDS_BYTES = 2 * 128 * 32 * 8 + (HY_CF_SRC + 1 + 2) * 128 * 16;
+
+// y: in = raw pass-2' values of rows 8h + l (h = g + 8 hh) at index 8 hh + l; out = canonical coefficient-form residues (times sc) of
+// rows g + 8k at index k
+template <class A>
+DEV void cf_inverse(const A ar, const ulonglong2 *__restrict__ tw, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs,
+                    u64 (&y)[16]) {
+    typedef typename A::T T;
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        const int h = g + 8 * hh;
+        T w[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) w[l] = A::from_bits(y[8 * hh + l]);
+#pragma unroll
+        for (int l = 0; l < 8; l += 2) ar.gs(w[l], w[l + 1], A::tw(ltw[64 + 4 * h + (l >> 1)]));
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+            if (!(l & 2)) ar.gs(w[l], w[l + 2], A::tw(ltw[32 + 2 * h + (l >> 2)]));
+        {
+            const typename A::TW W = A::tw(ltw[16 + h]);
+#pragma unroll
+            for (int l = 0; l < 4; l++) ar.gs(w[l], w[l + 4], W);
+        }
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            ar.recentre(w[l]);
+            lds[(8 * h + l) * 32 + col] = A::to_bits(w[l]);
+        }
+    }
+    __syncthreads();
+    T v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = A::from_bits(lds[(g + 8 * k) * 32 + col]);
+#pragma unroll
+    for (int st = 3; st >= 0; st--) {
+        const int h = 8 >> st;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (!(k & h)) ar.gs(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
+        if (st == 2) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) ar.mid(v[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) y[k] = ar.fin_inv(v[k], sc, scs);
+}
+DEV void cf_inverse_any(const NttTables &T, int m, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs, u64 (&y)[16]) {
+    const ModC M = T.mod[m];
+    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const ulonglong2 *__restrict__ tw = (fp ? T.itwf : T.itwp) + (size_t)m * 32768;
+    if (fp) cf_inverse<FpA>(FpA(M), tw, ltw, lds, g, col, sc, scs, y);
+    else if ((T.pm_mask >> m) & 1u) cf_inverse<IntP>(IntP(M), tw, ltw, lds, g, col, sc, scs, y);
+    else cf_inverse<IntA>(IntA(M), tw, ltw, lds, g, col, sc, scs, y);
+}
+// v: operands of rows g + 8k (this arithmetic's representation of canonical residues); the raw pass-1 image leaves through d
+template <class A>
+DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglong2 *ltw, u64 *lds, int g, int col,
+                    typename A::T (&v)[16], u64 *d) {
+    typedef typename A::T T;
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const int h = 8 >> st;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (!(k & h)) ar.ct(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[(g + 8 * k) * 32 + col] = A::to_bits(v[k]);
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        const int h = g + 8 * hh;
+        T w[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) w[l] = A::from_bits(lds[(8 * h + l) * 32 + col]);
+        {
+            const typename A::TW W = A::tw(ltw[16 + h]);
+#pragma unroll
+            for (int l = 0; l < 4; l++) ar.ct(w[l], w[l + 4], W);
+        }
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+            if (!(l & 2)) ar.ct(w[l], w[l + 2], A::tw(ltw[32 + 2 * h + (l >> 2)]));
+#pragma unroll
+        for (int l = 0; l < 8; l += 2) ar.ct(w[l], w[l + 1], A::tw(ltw[64 + 4 * h + (l >> 1)]));
+#pragma unroll
+        for (int l = 0; l < 8; l++) d[(size_t)(8 * h + l) * 256 + col] = A::to_bits(w[l]);  // raw: pass 2 finishes
+    }
+}
+// target value of row k: sum_s y_s f_s (+ the centred dropped limb) as the forward butterflies' operand.  Absent sources (a short
+// last digit) hold zeros, so the sum is branch-free: four lazy 128-bit multiply-accumulates.
+// Integer targets (the 60-bit limb 0): canonical residue, single-word Barrett on the top bits (reduce128k: at most four products of
+// residues below 2^60 with constants below q).
+template <class A, bool MDR>
+DEV void cf_convert(const A ar, const ModC &M, const u64 (&f)[HY_CF_SRC], const u64 (&y)[HY_CF_SRC][16], const u64 (&um)[16], unsigned neg,
+                    typename A::T (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u128 a = 0;
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) a += (u128)y[s][k] * f[s];
+        u64 r = reduce128k(a, M);
+        if (MDR) {
+            const u64 c = reduce64(um[k], M);
+            r = addmod(r, ((neg >> k) & 1u) ? negmod(c, M.q) : c, M.q);
+        }
+        v[k] = ar.from_canon(r);
+    }
+}
+// FP64 targets (q < 2^47): the transform is linear and exact on ANY representative below ~2 q in magnitude (growth 0.75 q per stage,
+// 15 stages, headroom 2^52), so the 128-bit sum a = a1 2^64 + a0h 2^32 + a0l (a1 < 2^46) is folded in FP64 instead of being reduced
+// to the canonical residue: a1 (2^64 mod q) and a0h 2^32 by exact FP64 products with one quotient each, a0l as it is — 16 instructions
+// instead of reduce128k + conversion (~32); |operand| <= 1.05 q (1.6 q with the dropped limb's centred residue).  The canonical
+// results after pass 2 are the same residues.
+template <bool MDR>
+DEV void cf_convert(const FpA ar, const ModC &M, const u64 (&f)[HY_CF_SRC], const u64 (&y)[HY_CF_SRC][16], const u64 (&um)[16], unsigned neg,
+                    double (&v)[16]) {
+    const double c64 = FpA::u2d(0ull - M.r64 * M.q);  // 2^64 mod q
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u128 a = 0;
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) a += (u128)y[s][k] * f[s];
+        const u64 a0 = (u64)a;
+        const double t1 = ar.mulmod2(FpA::u2d((u64)(a >> 64)), c64);
+        const double h = (double)(unsigned)(a0 >> 32) * 4294967296.0;  // exact
+        const double t0 = __fma_rn(-rint(h * ar.qinv), ar.q, h);
+        double r = t1 + t0 + (double)(unsigned)a0;
+        if (MDR) {
+            const double c = FpA::u2d(um[k]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
+            r += ((neg >> k) & 1u) ? -c : c;
+        }
+        v[k] = r;
+    }
+}
+
+// grid (8 column tiles, XP polynomials, ncf maps x target slices), 256 threads: col = t & 31, g = t >> 5
+template <bool MDR>
+__global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
+                                                           size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz) {
+    constexpr int N = 32768;
+    extern __shared__ __attribute__((aligned(16))) u64 cf_smem[];
+    u64 *const img = cf_smem;  // two exchange images of 128 x 32
+    ulonglong2 *const sltw = reinterpret_cast<ulonglong2 *>(cf_smem + 2 * 4096);  // [HY_CF_SRC + 1][128]
+    ulonglong2 *const tltw = sltw + (HY_CF_SRC + 1) * 128;                        // [2][128]
+    const int zi = blockIdx.z / slices, zs = blockIdx.z - zi * slices;
+    const ColFuse &cf = cfs[zi];
+    const int t_lo = zs * tz, t_hi = min(cf.nt, t_lo + tz);
+    if (t_lo >= t_hi) return;  // workgroup-uniform
+    const int t = threadIdx.x, col = t & 31, g = t >> 5;
+    const int xp = blockIdx.y, c0 = blockIdx.x * 32;
+    const u64 *sb = src + (size_t)xp * so + c0 + col;
+    // ---- every global load of the workgroup, up front
+    u64 y[HY_CF_SRC][16], um[16];
+#pragma unroll
+    for (int s = 0; s < HY_CF_SRC; s++)
+        if (s >= cf.nk) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) y[s][k] = 0;
+        } else {
+            const u64 *sp = sb + (size_t)cf.srow[s] * N;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int l = 0; l < 8; l++) y[s][8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+        }
+    if (MDR) {
+        const u64 *sp = sb + (size_t)cf.urow * N;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) um[8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+    }
+    if (t < 128) {
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++)
+            if (s < cf.nk) {
+                const int m = cf.smod[s];
+                const bool fp = T.twf != nullptr && T.mod[m].ks + 2 <= 47;
+                sltw[s * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
+            }
+        if (MDR) {
+            const int m = cf.umod;
+            const bool fp = T.twf != nullptr && T.mod[m].ks + 2 <= 47;
+            sltw[HY_CF_SRC * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
+        }
+    }
+    __syncthreads();
+    int buf = 0;
+    // ---- pass 1' of every source: raw -> canonical coefficient-form residues, in place in y / um
+    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, img + (buf ^= 1) * 4096, g, col, cf.ssc[0], cf.ssc_sh[0], y[0]);
+    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, img + (buf ^= 1) * 4096, g, col, cf.ssc[1], cf.ssc_sh[1], y[1]);
+    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, img + (buf ^= 1) * 4096, g, col, cf.ssc[2], cf.ssc_sh[2], y[2]);
+    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, img + (buf ^= 1) * 4096, g, col, cf.ssc[3], cf.ssc_sh[3], y[3]);
+    if (MDR) cf_inverse_any(T, cf.umod, sltw + HY_CF_SRC * 128, img + (buf ^= 1) * 4096, g, col, cf.usc, cf.usc_sh, um);
+    // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
+    unsigned neg = 0;
+    if (MDR) {
+        const ModC Ml = T.mod[cf.l];
+        const u64 half = Ml.q >> 1;
+        u64 fl[HY_CF_SRC];
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) fl[s] = s < cf.nk ? cf.fl[s] : 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            u128 a = 0;
+#pragma unroll
+            for (int s = 0; s < HY_CF_SRC; s++) a += (u128)y[s][k] * fl[s];
+            const u64 yl = submod(um[k], reduce128k(a, Ml), Ml.q);
+            const bool ng = yl > half;
+            um[k] = ng ? Ml.q - yl : yl;
+            neg |= (ng ? 1u : 0u) << k;
+        }
+    }
+    // ---- every target of this slice: conversion, pass 1, raw image out
+    for (int tt = t_lo; tt < t_hi; tt++) {
+        const int m = cf.tmod[tt];
+        const ModC M = T.mod[m];
+        const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+        const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
+        ulonglong2 *ltw = tltw + (tt & 1) * 128;
+        if (t < 128) ltw[t] = tw[t];
+        u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;  // cf_forward adds the lane's column
+        u64 *lds = img + (buf ^= 1) * 4096;
+        u64 f[HY_CF_SRC];
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) f[s] = s < cf.nk ? cf.f[s][tt] : 0;
+        if (fp) {
+            const FpA ar(M);
+            double v[16];
+            cf_convert<MDR>(ar, M, f, y, um, neg, v);
+            cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
+        } else if ((T.pm_mask >> m) & 1u) {
+            const IntP ar(M);
+            u64 v[16];
+            cf_convert<IntP, MDR>(ar, M, f, y, um, neg, v);
+            cf_forward<IntP>(ar, tw, ltw, lds, g, col, v, d);
+        } else {
+            const IntA ar(M);
+            u64 v[16];
+            cf_convert<IntA, MDR>(ar, M, f, y, um, neg, v);
+            cf_forward<IntA>(ar, tw, ltw, lds, g, col, v, d);
+        }
+    }
+}
+
+}  // namespace
+
+namespace hk {
+
+void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
+                   const ColFuse *h_cf, int ncf) {
+    static bool attr_done[64][2] = {};  // > 64 KiB of dynamic LDS has to be granted per kernel and per device
+    const bool mdr = h_cf[0].mdr != 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev][mdr]) {
+        if (mdr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt15_colfuse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS_BYTES);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt15_colfuse<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS_BYTES);
+        attr_done[dev][mdr] = true;
+    }
+    int nt_max = 0;
+    double rows = 0;  // sources in, targets out, each once
+    for (int i = 0; i < ncf; i++) {
+        nt_max = std::max(nt_max, h_cf[i].nt);
+        rows += h_cf[i].nk + (h_cf[i].mdr ? 1 : 0) + h_cf[i].nt;
+    }
+    ledger_add(mdr ? "k_ntt15_colfuse<true>" : "k_ntt15_colfuse<false>", rows * XP * 262144.0);
+    // launches that cannot fill the chip (a one-block query's tail) slice their targets over grid.z: every slice repeats the sources'
+    // inverse transforms (from L2) and serves tz targets, so the serial chain per workgroup shrinks with the launch
+    const int base = 8 * XP * ncf;
+    int slices = 1;
+    if (base < 512) slices = std::min(nt_max, (512 + base - 1) / base);
+    const int tz = (nt_max + slices - 1) / slices;
+    slices = (nt_max + tz - 1) / tz;
+    if (mdr)
+        hipLaunchKernelGGL((k_ntt15_colfuse<true>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz);
+    else
+        hipLaunchKernelGGL((k_ntt15_colfuse<false>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz);
+}
+
+}  // namespace hk

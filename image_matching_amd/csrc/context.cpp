@@ -368,6 +368,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
     fuse_loop_a = getenv("HYDIA_NO_FUSE_LOOPA") == nullptr;
+    colfuse = getenv("HYDIA_NO_COLFUSE") == nullptr;
     if (const char *e = getenv("HYDIA_SLICE_MIB")) slice_bytes = (size_t)atol(e) << 20;
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
@@ -391,6 +392,8 @@ Context::~Context() {
     pool.trim();
     for (auto &kv : modup_plans)
         if (kv.second.d_tabs) (void)hipFree(kv.second.d_tabs);
+    for (auto &kv : cf_plans)
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
     rot_keys[0] = relin_key;
     for (auto &kv : rot_keys)
         if (!kv.second.borrowed)

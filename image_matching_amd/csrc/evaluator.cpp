@@ -65,6 +65,113 @@ const Context::ModUpPlan &Context::modup_plan(int nl) {
     return modup_plans.emplace(nl, std::move(pl)).first->second;
 }
 
+// ---- column-fused conversion plans (colfuse.hip): the constants of the unfused kernels, regrouped per (sources -> targets) map
+const Context::CfPlan &Context::cf_plan_store(const std::string &key, std::vector<ColFuse> &&maps) {
+    CfPlan pl;
+    pl.host = std::move(maps);
+    HIP_CHECK(hipMalloc((void **)&pl.dev, sizeof(ColFuse) * pl.host.size()));
+    HIP_CHECK(hipMemcpy(pl.dev, pl.host.data(), sizeof(ColFuse) * pl.host.size(), hipMemcpyHostToDevice));
+    return cf_plans.emplace(key, std::move(pl)).first->second;
+}
+// ModUp at level nl: map d = digit d, sources = the digit's own limbs (inverse scale N^{-1} (D/q_j)^{-1}), targets = every other
+// limb of Q_l u P, written to row d*nE + t of the polynomial's digit block
+const Context::CfPlan &Context::cf_plan_modup(int nl) {
+    const std::string key = "mu:" + std::to_string(nl);
+    auto it = cf_plans.find(key);
+    if (it != cf_plans.end()) return it->second;
+    const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
+    const LimbSel esel = sel_ext(nl);
+    const ModUpPlan &pl = modup_plan(nl);
+    std::vector<ConvTab> tabs(nd);
+    HIP_CHECK(hipMemcpy(tabs.data(), pl.d_tabs, sizeof(ConvTab) * nd, hipMemcpyDeviceToHost));
+    std::vector<ColFuse> maps(nd);
+    for (int d = 0; d < nd; d++) {
+        const int lo = d * alpha, hi = std::min(lo + alpha, nl);
+        ColFuse &cf = maps[d];
+        cf = ColFuse{};
+        cf.nk = hi - lo;
+        for (int s = 0; s < cf.nk; s++) {
+            const u64 qq = q[lo + s];
+            cf.smod[s] = lo + s;
+            cf.srow[s] = lo + s;
+            cf.ssc[s] = mulmod_u64(pl.inv[lo + s] % qq, mod[lo + s].ninv, qq);
+            cf.ssc_sh[s] = shoup_h(cf.ssc[s], qq);
+        }
+        for (int t = 0; t < nE; t++) {
+            if (t >= lo && t < hi) continue;
+            if (cf.nt >= HY_CF_TGT) throw std::runtime_error("hydia: too many ModUp targets for the column-fused conversion");
+            cf.tmod[cf.nt] = esel.mod[t];
+            cf.trow[cf.nt] = d * nE + t;
+            for (int s = 0; s < cf.nk; s++) cf.f[s][cf.nt] = tabs[d].f[s][t];
+            cf.nt++;
+        }
+    }
+    return cf_plan_store(key, std::move(maps));
+}
+// ModDown at level nl: sources = the special-prime limbs (rows 0..nP-1, inverse scale N^{-1} (P/p_k)^{-1}), targets = limbs 0..nl-1
+const Context::CfPlan &Context::cf_plan_moddown(int nl, bool premul) {
+    const std::string key = std::string(premul ? "mdp:" : "md:") + std::to_string(nl);
+    auto it = cf_plans.find(key);
+    if (it != cf_plans.end()) return it->second;
+    if (nl > HY_CF_TGT) throw std::runtime_error("hydia: too many ModDown targets for the column-fused conversion");
+    std::vector<ColFuse> maps(1);
+    ColFuse &cf = maps[0];
+    cf = ColFuse{};
+    cf.nk = nP;
+    cf.nt = nl;
+    for (int k = 0; k < nP; k++) {
+        const u64 qq = q[nQ + k];
+        cf.smod[k] = nQ + k;
+        cf.srow[k] = k;
+        cf.ssc[k] = mulmod_u64(Phat_inv[k] % qq, mod[nQ + k].ninv, qq);
+        cf.ssc_sh[k] = shoup_h(cf.ssc[k], qq);
+        for (int j = 0; j < nl; j++) cf.f[k][j] = premul ? mulmod_u64(Phat_mod_q[k][j], Pinv_mod_q[j], q[j]) : Phat_mod_q[k][j];
+    }
+    for (int j = 0; j < nl; j++) {
+        cf.tmod[j] = j;
+        cf.trow[j] = j;
+    }
+    return cf_plan_store(key, std::move(maps));
+}
+// merged ModDown + Rescale from level nl (l = nl - 1 dropped): sources = row 0 the dropped limb u (N^{-1}), rows 1..nP the special-prime
+// limbs; constants with P^{-1} (and the doubling) folded in; targets = limbs 0..l-1
+const Context::CfPlan &Context::cf_plan_moddown_rescale(int nl, bool dbl) {
+    const std::string key = std::string(dbl ? "mdr2:" : "mdr:") + std::to_string(nl);
+    auto it = cf_plans.find(key);
+    if (it != cf_plans.end()) return it->second;
+    const int l = nl - 1;
+    if (l > HY_CF_TGT) throw std::runtime_error("hydia: too many targets for the column-fused conversion");
+    std::vector<ColFuse> maps(1);
+    ColFuse &cf = maps[0];
+    cf = ColFuse{};
+    cf.nk = nP;
+    cf.nt = l;
+    cf.mdr = 1;
+    cf.l = l;
+    cf.umod = l;
+    cf.urow = 0;
+    cf.usc = mod[l].ninv;
+    cf.usc_sh = mod[l].ninv_sh;
+    for (int k = 0; k < nP; k++) {
+        const u64 qq = q[nQ + k];
+        cf.smod[k] = nQ + k;
+        cf.srow[k] = 1 + k;
+        cf.ssc[k] = mulmod_u64(Phat_inv[k] % qq, mod[nQ + k].ninv, qq);
+        cf.ssc_sh[k] = shoup_h(cf.ssc[k], qq);
+        for (int j = 0; j < nl; j++) {
+            u64 f = mulmod_u64(Phat_mod_q[k][j], Pinv_mod_q[j], q[j]);
+            if (dbl) f = (f + f) % q[j];
+            if (j < l) cf.f[k][j] = f;
+            else cf.fl[k] = f;
+        }
+    }
+    for (int j = 0; j < l; j++) {
+        cf.tmod[j] = j;
+        cf.trow[j] = j;
+    }
+    return cf_plan_store(key, std::move(maps));
+}
+
 // ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
 // extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
 // NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.  One inverse transform and one conversion
@@ -77,6 +184,34 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
     const LimbSel esel = sel_ext(nl), qsel = sel_q(nl);
     const ModUpPlan &pl = modup_plan(nl);
     u64 *y = pool.get((size_t)X * nl * N * sizeof(u64));
+    if (cf_ok()) {
+        // inverse pass 2' of every limb, then ONE column-fused launch: pass 1' of a digit's limbs, conversion, pass 1 of its targets
+        const CfPlan &cp = cf_plan_modup(nl);
+        hk::ntt15_inverse_p2(stream, tabs, c, y, c_outer, (size_t)nl * N, X, qsel);
+        hk::ntt15_colfuse(stream, tabs, y, (size_t)nl * N, dig, dig_x, X, cp.dev, cp.host.data(), nd);
+        pool.put(y);
+        if (!p1_only) {
+            if ((size_t)X * nd * nE < 128) {  // small launch: one second pass over every row (the own rows hold garbage nobody reads)
+                hk::ntt15_forward_p2(stream, tabs, dig, (size_t)nE * N, X * nd, esel);
+            } else {
+                for (int d = 0; d < nd; d++) {
+                    const int lo = d * alpha, hi = std::min(lo + alpha, nl);
+                    u64 *out = dig + (size_t)d * nE * N;
+                    LimbSel rest{};
+                    rest.n = nE - hi;
+                    for (int t = hi; t < nE; t++) rest.mod[t - hi] = esel.mod[t];
+                    if (lo > 0) hk::ntt15_forward_p2(stream, tabs, out, dig_x, X, sel_range(0, lo));
+                    if (rest.n > 0) hk::ntt15_forward_p2(stream, tabs, out + (size_t)hi * N, dig_x, X, rest);
+                }
+            }
+        }
+        if (copy_own)
+            for (int d = 0; d < nd; d++) {
+                const int lo = d * alpha, hi = std::min(lo + alpha, nl);
+                hk::copy_limbs(stream, N, c + (size_t)lo * N, dig + (size_t)d * nE * N + (size_t)lo * N, c_outer, dig_x, X, hi - lo);
+            }
+        return;
+    }
     ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
     const bool fused_conv = prm.logN == 15 && fuse_bconv;
     if (!fused_conv) hk::base_convert_digits(stream, d_mod, N, y, (size_t)nl * N, dig, dig_x, X, pl.d_tabs, nd, nl, nE, esel);
@@ -167,17 +302,24 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
                 lp.packed_nQ = keys_packed_nQ;
                 lp.key_row0 = nQ;
                 lp.dig_row0 = nl;
-                hk::ntt15_inverse_loop_a(stream, tabs, y, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true), lp);
+                hk::ntt15_inverse_loop_a(stream, tabs, y, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true), lp, /*p1=*/!cf_ok());
             } else {
                 u64 *accp = pool.get((size_t)Xc * 2 * nP * N * sizeof(u64));
                 timer_begin("ks_inner_product");
                 hk::inner_product(stream, d_mod, N, dig, 0, nd, d_keys + x0, 0, nT, accp, Xc, psel, nullptr, 0, 1, 0, nP, keys_packed_nQ, nE, nl);
                 timer_end("ks_inner_product");
-                ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true));
+                if (cf_ok()) hk::ntt15_inverse_p2(stream, tabs, accp, y, (size_t)nP * N, (size_t)nP * N, Xc * 2, psel);
+                else ntt_inv(accp, y, (size_t)nP * N, (size_t)nP * N, Xc * 2, psel, scale_of(psel, Phat_inv, true));
                 pool.put(accp);
             }
+            const bool cfu = cf_ok();
             u64 *conv = pool.get((size_t)Xc * 2 * nl * N * sizeof(u64));
-            hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, Xc * 2, tab, qsel);
+            if (cfu) {
+                const CfPlan &cp = cf_plan_moddown(nl, premul);
+                hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, Xc * 2, cp.dev, cp.host.data(), 1);
+            } else {
+                hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, Xc * 2, tab, qsel);
+            }
             pool.put(y);
             NttLoad ld{};
             NttStore stp{};
@@ -199,7 +341,8 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
             stp.la.packed_nQ = keys_packed_nQ;
             stp.la.premul = premul ? 1 : 0;
             stp.la.fp = loop_a_int_ip ? 0 : 1;
-            hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
+            if (cfu) hk::ntt15_forward_p2_fused(stream, tabs, conv, (size_t)nl * N, Xc * 2, qsel, stp);
+            else hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
             pool.put(conv);
         }
         return;
@@ -210,8 +353,33 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     timer_end("ks_inner_product");
     // P limbs -> coefficient form, pre-multiplied by (P/p_k)^{-1}
     u64 *y = pool.get((size_t)X * 2 * nP * N * sizeof(u64));
-    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
     u64 *conv = pool.get((size_t)X * 2 * nl * N * sizeof(u64));
+    if (cf_ok()) {
+        // special-prime limbs: pass 2' alone, then pass 1' + conversion + pass 1 in one column-fused launch, then pass 2 + ModDown combine
+        const CfPlan &cp = cf_plan_moddown(nl, false);
+        hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel);
+        hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, cp.dev, cp.host.data(), 1);
+        NttStore stp{};
+        stp.mode = 1;
+        stp.out = out;
+        stp.nl = nl;
+        stp.in = acc;
+        stp.in_ls = nE;
+        stp.mul = scale_of(qsel, pinv, false);
+        stp.addend = addend;
+        stp.add_x = add_x_stride;
+        stp.add_p = add_poly_stride;
+        stp.add_polys = add_polys;
+        stp.dbl = dbl ? 1 : 0;
+        stp.ginv = d_ginv;
+        stp.same_g = same_galois;
+        hk::ntt15_forward_p2_fused(stream, tabs, conv, (size_t)nl * N, X * 2, qsel, stp);
+        pool.put(conv);
+        pool.put(y);
+        pool.put(acc);
+        return;
+    }
+    ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
     if (prm.logN == 15) {
         // ModDown combine (+ addend, doubling, automorphism scatter) fused into the NTT's second pass; the P -> Q base
         // conversion runs as its own all-targets kernel unless HYDIA_FUSE_BCONV asks for the first-pass fusion
@@ -436,10 +604,13 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
         tail.mod[1 + k] = nQ + k;
         tail_scale[1 + k] = Phat_inv[k];
     }
+    const bool cfu = cf_ok() && (q[l] >> 50) == 0;  // the fused kernel carries the dropped limb's centred residue as a double
     if (fused_tail) {
         hk::ntt15_inverse_p2_last_limb(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
                                        c.d, c.ct_elems(), c.poly_elems(), dbl ? 1 : 0);
-        hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+        if (!cfu) hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+    } else if (cfu) {
+        hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail);
     } else {
         ntt_inv(acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
     }
@@ -454,7 +625,12 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
             tab.f[k][j] = dbl ? (f + f) % q[j] : f;
         }
     u64 *w = pool.get((size_t)XP * l * N * sizeof(u64));
-    hk::moddown_rescale_conv(stream, d_mod, N, y, yu_outer, u, yu_outer, w, XP, l, nP, tab);
+    if (cfu) {  // pass 1' of u and the special-prime limbs, the correction of every remaining limb and its pass 1: one launch
+        const CfPlan &cp = cf_plan_moddown_rescale(nl, dbl);
+        hk::ntt15_colfuse(stream, tabs, yu, yu_outer, w, (size_t)l * N, XP, cp.dev, cp.host.data(), 1);
+    } else {
+        hk::moddown_rescale_conv(stream, d_mod, N, y, yu_outer, u, yu_outer, w, XP, l, nP, tab);
+    }
     const LimbSel qsel = sel_q(l);
     const double out_scale = c.scale / (double)q[l];
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
@@ -479,7 +655,8 @@ void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const do
     stp.npoly = 2;
     if (addc)
         for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out_scale, q[j]);
-    hk::ntt15_forward_fused(stream, tabs, w, w, (size_t)l * N, (size_t)l * N, XP, qsel, ld, stp);
+    if (cfu) hk::ntt15_forward_p2_fused(stream, tabs, w, (size_t)l * N, XP, qsel, stp);
+    else hk::ntt15_forward_fused(stream, tabs, w, w, (size_t)l * N, (size_t)l * N, XP, qsel, ld, stp);
     pool.put(w);
     pool.put(yu);
     pool.put(acc);

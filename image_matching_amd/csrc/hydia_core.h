@@ -183,6 +183,19 @@ struct Context : HostParams {
     };
     std::map<int, ModUpPlan> modup_plans;
     const ModUpPlan &modup_plan(int nl);
+    // column-fused conversions (colfuse.hip): the (sources -> targets) maps of a ModUp (one per digit), a ModDown, loop A's ModDown
+    // and the merged ModDown + Rescale at one level, in host and device memory
+    struct CfPlan {
+        std::vector<ColFuse> host;
+        ColFuse *dev = nullptr;
+    };
+    std::map<std::string, CfPlan> cf_plans;
+    const CfPlan &cf_plan_modup(int nl);
+    const CfPlan &cf_plan_moddown(int nl, bool premul);          // premul: constants carry P^{-1} (loop A's pre-scaled key shadow)
+    const CfPlan &cf_plan_moddown_rescale(int nl, bool dbl);     // merged ModDown + Rescale from level nl
+    const CfPlan &cf_plan_store(const std::string &key, std::vector<ColFuse> &&maps);
+    bool colfuse = true;        // HYDIA_NO_COLFUSE: pass 1' / conversion / pass 1 as three kernels
+    bool cf_ok() const { return colfuse && prm.logN == 15 && alpha <= HY_CF_SRC && nP <= HY_CF_SRC && !fuse_bconv; }
     LimbSel sel_q(int nl) const;           // limbs 0..nl-1
     LimbSel sel_ext(int nl) const;         // limbs 0..nl-1 then all P limbs
     LimbSel sel_range(int lo, int hi) const;

@@ -123,6 +123,25 @@ struct NttStore {
 };
 
 
+// Column-fused conversion (k_ntt15_colfuse, N = 2^15): inverse pass 1' of up to 4 source limbs (+ the dropped limb of a merged
+// ModDown + Rescale), fast base conversion, forward pass 1 of up to 16 target limbs — all on ONE 32-column tile of the 128 x 256
+// coefficient matrix, sources held in registers, so the coefficient-form rows never exist in HBM.  One entry describes one
+// (sources -> targets) map: a ModDown, or one digit of a ModUp.
+#define HY_CF_SRC 4
+#define HY_CF_TGT 16
+struct ColFuse {
+    int nk, nt;                  // conversion sources, targets
+    int mdr;                     // 1: merged ModDown + Rescale — an extra source `u` (modulus l) whose centred residue is added to every target
+    int l;                       // mdr: modulus id of the dropped limb
+    int smod[HY_CF_SRC], srow[HY_CF_SRC];  // modulus id / row (in src, per polynomial) of each conversion source
+    int umod, urow;                        // mdr: the same for u
+    u64 ssc[HY_CF_SRC], ssc_sh[HY_CF_SRC]; // final multiplier of each source's inverse transform (N^{-1} x conversion factor)
+    u64 usc, usc_sh;
+    int tmod[HY_CF_TGT], trow[HY_CF_TGT];  // modulus id / row (in dst, per polynomial) of each target
+    u64 f[HY_CF_SRC][HY_CF_TGT];           // conversion constants: target t = sum_k y_k f[k][t] mod q_tmod[t]
+    u64 fl[HY_CF_SRC];                     // mdr: constants of the dropped limb, y_l = u - sum_k y_k fl[k] mod q_l
+};
+
 // resident database layout: ciphertext t at t*ct_bytes, polynomial p at + p*poly_bytes, limb 0 as N 8-byte residues, then
 // (packed) limbs 1.. as N 6-byte residues each — or plain [2][nQ][N] u64 when not packed
 struct DbLayout {
@@ -181,7 +200,7 @@ void ntt15_forward(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
                    const LimbSel &sel);
 // inverse transform whose INPUT is loop A's inner product over the limbs of sel (formed in the first pass's load, never in HBM)
 void ntt15_inverse_loop_a(hipStream_t st, const NttTables &T, u64 *dst, size_t dst_outer, int X, const LimbSel &sel,
-                          const ScaleSel &scale, const LoopAIp &la);
+                          const ScaleSel &scale, const LoopAIp &la, bool p1 = true);
 void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X,
                    const LimbSel &sel, const ScaleSel &scale);
 // forward transform with fused prologue / epilogue; dst is the [X][sel.n][N] scratch between the passes
@@ -244,6 +263,13 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
                             int nl, int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
                             u64 *inv_out = nullptr, size_t inv_outer = 0, int inv_row0 = 0);
 void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel);
+// second pass alone, in place on pass-1 output (plain store)
+void ntt15_forward_p2(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel);
+void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const NttStore &stp);
+// column-fused conversion: src [XP][..][N] holds the raw image of the sources' inverse pass 2', dst [XP][..][N] receives the raw
+// pass-1 image of the targets (pass 2 finishes it).  d_cf: ncf maps in device memory (h_cf: host copy), map z serves every polynomial
+void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
+                   const ColFuse *h_cf, int ncf);
 // out[x][p][j][c'] = ((acc[x][p][j][c] - conv[x][p][j][c]) * pinv[j] + (addend ? addend[x*add_x + p*add_ps + j*N + c] : 0)),
 // c = perm_g(c') when galois[x] != 1 (evaluation-form automorphism), acc rows have stride acc_limbs*N
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,

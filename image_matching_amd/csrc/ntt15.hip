@@ -18,150 +18,13 @@
 // Pass-1 phase-A twiddles are workgroup-uniform; the remaining pass-1 twiddles sit in 2 KiB of LDS; pass-2 twiddles are
 // 16-byte pair loads shared by the TWO polynomials a workgroup transforms together.
 #include "kernels.h"
+#include "ntt_arith.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 namespace {
-
-struct IntA {
-    typedef u64 T;
-    typedef ulonglong2 TW;  // (w, floor(w 2^64 / q))
-    u64 q, q2;
-    DEV IntA(const ModC &M) : q(M.q), q2(2 * M.q) {}
-    DEV static TW tw(const ulonglong2 b) { return b; }
-    DEV T from_canon(u64 x) const { return x; }
-    DEV static T from_bits(u64 x) { return x; }
-    DEV static u64 to_bits(T x) { return x; }
-    DEV void ct(T &a, T &b, const TW W) const {  // [0,4q) -> [0,4q)
-        const u64 u = a >= q2 ? a - q2 : a;
-        const u64 hi = __umul64hi(b, W.y);
-        const u64 t = b * W.x - hi * q;
-        a = u + t;
-        b = u - t + q2;
-    }
-    DEV void gs(T &a, T &b, const TW W) const {  // [0,2q) -> [0,2q)
-        u64 s = a + b;
-        s = s >= q2 ? s - q2 : s;
-        const u64 d = a - b + q2;
-        const u64 hi = __umul64hi(d, W.y);
-        b = d * W.x - hi * q;
-        a = s;
-    }
-    DEV void recentre(T &) const {}
-    DEV void recentre_wide(T &) const {}
-    DEV void mid(T &) const {}
-    DEV T from_raw(u64 x) const { return x; }
-    DEV u64 fin_fwd(T x) const {
-        x = x >= q2 ? x - q2 : x;
-        return x >= q ? x - q : x;
-    }
-    DEV u64 fin_inv(T x, u64 sc, u64 scs) const { return mulmod_shoup(x, sc, scs, q); }
-};
-
-// q = 2^60 - c with c < 2^24 (every 60-bit prime OpenFHE picks for this parameter set): values live lazily in [0, 16q) = [0, 2^64 - 16c)
-// and a conditional subtraction (five instructions per butterfly) becomes an occasional three-instruction fold x -> (x mod 2^60) +
-// (x >> 60) c, which lands any 64-bit x in [0, 2^60 + 15c] inside [0, 2q).  Forward (Cooley-Tukey): a Shoup product of ANY b < 2^64 is in
-// [0, 2q), a' = a + t and b' = a - t + 2q grow the bound by 2q per stage: q -> 15q over pass 1's seven stages, fold on reading pass 1's
-// output, 2q -> 8q -> 14q over phases A and B, fold, 6q after phase C, fold + one subtraction to the canonical residue.  Inverse
-// (Gentleman-Sande): sums double, d = a - b + 8q needs b < 8q, so at most three stages run between folds (the hooks the FP64 path
-// re-centres at, plus one inside pass 1's four-stage group).  Same residues as IntA after the final reduction.
-struct IntP {
-    typedef u64 T;
-    typedef ulonglong2 TW;
-    u64 q, q2, q8;
-    unsigned c;
-    DEV IntP(const ModC &M) : q(M.q), q2(2 * M.q), q8(8 * M.q), c((unsigned)((1ull << 60) - M.q)) {}
-    DEV static TW tw(const ulonglong2 b) { return b; }
-    DEV T from_canon(u64 x) const { return x; }
-    DEV static T from_bits(u64 x) { return x; }
-    DEV static u64 to_bits(T x) { return x; }
-    DEV u64 fold(u64 x) const { return (x & ((1ull << 60) - 1)) + (u64)(unsigned)(x >> 60) * c; }
-    DEV void ct(T &a, T &b, const TW W) const {
-        const u64 hi = __umul64hi(b, W.y);
-        const u64 t = b * W.x - hi * q;
-        const u64 u = a;
-        a = u + t;
-        b = u - t + q2;
-    }
-    DEV void gs(T &a, T &b, const TW W) const {
-        const u64 s = a + b;
-        const u64 d = a - b + q8;
-        const u64 hi = __umul64hi(d, W.y);
-        b = d * W.x - hi * q;
-        a = s;
-    }
-    DEV void recentre(T &x) const { x = fold(x); }
-    DEV void recentre_wide(T &x) const { x = fold(x); }
-    DEV void mid(T &x) const { x = fold(x); }
-    DEV T from_raw(u64 x) const { return fold(x); }
-    DEV u64 fin_fwd(T x) const {
-        x = fold(x);
-        return x >= q ? x - q : x;
-    }
-    DEV u64 fin_inv(T x, u64 sc, u64 scs) const { return mulmod_shoup(x, sc, scs, q); }
-};
-
-struct FpA {
-    typedef double T;
-    typedef double2 TW;  // (w, w / q)
-    double q, qinv;
-    bool lean;  // q < 2^45 (1 + 1/16), true for every scaling prime of the default chain: 32 q stays below 2^50.1
-    DEV FpA(const ModC &M) : q((double)M.q), qinv(1.0 / (double)M.q), lean(M.q < (1ull << 45) + (1ull << 41)) {}
-    DEV static TW tw(const ulonglong2 b) { return make_double2(__longlong_as_double((long long)b.x), __longlong_as_double((long long)b.y)); }
-    // twiddle given alone: w / q as w * (1/q).  The quotient estimate of mulmod may then be off by one more in rare cases: the result
-    // stays an exact representative of a*w (|r| <= ~1.3 q instead of 0.75 q), which the transforms' headroom (< 2^52) absorbs
-    DEV TW tw8(const double wv) const { return make_double2(wv, wv * qinv); }
-    // integer <-> double without the emulated 64-bit conversions: for 0 <= x < 2^52 the bit pattern 0x433.. | x IS the double 2^52 + x
-    DEV static double u2d(u64 x) { return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0; }
-    DEV static u64 d2u(double r) { return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull; }  // r integral in [0, 2^52)
-    DEV T from_canon(u64 x) const { return u2d(x); }  // x < 2^47: exact
-    DEV static T from_bits(u64 x) { return __longlong_as_double((long long)x); }
-    DEV static u64 to_bits(T x) { return (u64)__double_as_longlong(x); }
-    DEV double mulmod(const double v, const TW W) const {  // exact v*w - c*q with |result| <= 0.75 q
-        const double h = v * W.x;
-        const double l = __fma_rn(v, W.x, -h);
-        const double c = rint(v * W.y);
-        return __fma_rn(-c, q, h) + l;
-    }
-    // exact a*b - c*q for canonical a, b < q < 2^47 (no precomputed b / q): |result| <= 0.55 q
-    DEV double mulmod2(const double a, const double b) const {
-        const double h = a * b;
-        const double l = __fma_rn(a, b, -h);
-        const double c = rint(h * qinv);
-        return __fma_rn(-c, q, h) + l;
-    }
-    DEV void ct(T &a, T &b, const TW W) const {
-        const double r = mulmod(b, W);
-        b = a - r;
-        a = a + r;
-    }
-    DEV void gs(T &a, T &b, const TW W) const {
-        const double s = a + b, d = a - b;
-        b = mulmod(d, W);
-        a = s;
-    }
-    DEV void recentre(T &x) const { x = __fma_rn(-rint(x * qinv), q, x); }  // -> [-q/2, q/2]
-    // The inverse transform doubles magnitudes on its sum path; a reduction every 3-4 stages keeps 47-bit primes below 2^52.  For
-    // the lean primes two of the four reductions of the two-pass inverse can go: runs of 5 and 6 stages reach 32 q < 2^50.1, where
-    // products and quotient estimates are still exact enough (|quotient error| <= 1, results exact).  Final residues are unchanged.
-    DEV void recentre_wide(T &x) const {
-        if (!lean) recentre(x);
-    }
-    DEV void mid(T &) const {}
-    DEV T from_raw(u64 x) const { return from_bits(x); }
-    DEV u64 fin_fwd(T x) const {
-        recentre(x);
-        if (x < 0) x += q;
-        return d2u(x);
-    }
-    DEV u64 fin_inv(T x, u64 sc, u64) const {
-        const double s = u2d(sc);
-        double r = mulmod(x, make_double2(s, s * qinv));
-        if (r < 0) r += q;
-        return d2u(r);
-    }
-};
 
 // ------------------------------------------------------------------------------------------------ fused prologues
 // canonical coefficient-form value of element `idx` (inside the limb-poly) of target limb `slot` for polynomial x
@@ -1367,6 +1230,18 @@ void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *d
     NttLoad ld{};
     launch_p1_fwd<0>(st, T, src, dst, so, dso, X, sel, 0, sel.n, ld);
 }
+void ntt15_forward_p2(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel) {
+    NttStore stp{};
+    launch_p2_fwd<0>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+}
+// second pass alone with a fused epilogue (the first pass ran inside the column-fused conversion)
+void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const NttStore &stp) {
+    if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else if (stp.mode == 5) launch_p2_fwd<5>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else launch_p2_fwd<0>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+}
 void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                          const LimbSel &sel, const NttLoad &ld, const NttStore &stp) {
     if (ld.mode == 1) {  // base conversion inside pass 1 (HYDIA_FUSE_BCONV experiment): two-pass kernels only
@@ -1389,7 +1264,7 @@ void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64
     else forward_runs<0, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);
 }
 void ntt15_inverse_loop_a(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const ScaleSel &scale,
-                          const LoopAIp &la) {
+                          const LoopAIp &la, bool p1) {
     NttLoad ld{};
     NttStore stp{};
     stp.mode = 5;
@@ -1401,13 +1276,14 @@ void ntt15_inverse_loop_a(hipStream_t st, const NttTables &T, u64 *dst, size_t d
             keyb += la.nd * 32768.0 * ((la.packed_nQ > 0 && j > 0 && j < la.packed_nQ) ? 6.0 : 8.0);
         }
         ledger_add((X % 2 == 0) ? "k_ntt15_p2<true, 2, 5>" : "k_ntt15_p2<true, 1, 5>", (double)X * (keyb + sel.n * 262144.0));
-        ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * sel.n * 262144.0);
+        if (p1) ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * sel.n * 262144.0);
     }
     if (X % 2 == 0)
         hipLaunchKernelGGL((k_ntt15_p2<true, 2, 5>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<true, 1, 5>), dim3(16, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, stp);
-    hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, scale, ld);
+    // p1 = false: the column-fused conversion that follows runs pass 1' itself
+    if (p1) hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, scale, ld);
 }
 void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel) {
     NttStore stp{};

@@ -282,7 +282,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     variants = [
         {},
         {"HYDIA_NTT_INT": "1", "HYDIA_DB_UNPACKED": "1", "HYDIA_KEYS_UNPACKED": "1", "HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1",
-         "HYDIA_LANES": "1", "HYDIA_NO_FORK": "1", "HYDIA_NO_FUSE_LOOPA": "1"},
+         "HYDIA_LANES": "1", "HYDIA_NO_FORK": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_NO_COLFUSE": "1"},
         {"HYDIA_NO_FUSE_IP": "1", "HYDIA_LANES": "3"},
         {"HYDIA_NTT_1PASS": "1", "HYDIA_NTT_1PASS_MIN": "1"},  # the one-pass kernel (one HBM round trip) for every FP64 limb transform
         {"HYDIA_NTT_1PASS": "1"},  # ... only for launches of at least 1024 limb-polynomials
@@ -290,6 +290,8 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         # kernel, the relinearisation's special-prime rows through the accumulator, unsliced conversion targets, paired small transforms
         {"HYDIA_MODUP_PER_DIGIT": "1", "HYDIA_LOOPA_SEPARATE_IP": "1", "HYDIA_RELIN_SEPARATE_INTT": "1", "HYDIA_LOOPA_INT_IP": "1"},
         {"HYDIA_NTT_NO_PM": "1", "HYDIA_RELIN_TWO_IP_LAUNCHES": "1"},
+        # round 3: pass 1' / base conversion / pass 1 as three kernels instead of the column-fused one (default arithmetics)
+        {"HYDIA_NO_COLFUSE": "1"},
         # the unfused pipeline on the default arithmetics (FP64 + lazy pseudo-Mersenne butterflies through the plain epilogues)
         {"HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_KEYS_UNPACKED": "1"},  # Harvey [0, 4q) butterflies for the 60-bit primes; two inner-product launches
     ]
@@ -302,7 +304,8 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     for env in variants:
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
                   "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA", "HYDIA_MODUP_PER_DIGIT",
-                  "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP", "HYDIA_NTT_NO_PM", "HYDIA_RELIN_TWO_IP_LAUNCHES"):
+                  "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP", "HYDIA_NTT_NO_PM", "HYDIA_RELIN_TWO_IP_LAUNCHES",
+                  "HYDIA_NO_COLFUSE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
