@@ -120,8 +120,8 @@ int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const
 }
 void hydia_ctx_destroy(hydia_ctx *ctx) {
     if (!ctx) return;
-    if (ctx->live_handles > 0) ctx->destroy_requested = true;
-    else delete ctx;
+    use_device(ctx);
+    if (ctx->refs.fetch_sub(1) == 1) delete ctx;  // otherwise the last hydia_ct_free does it
 }
 int hydia_get_info(const hydia_ctx *ctx, hydia_info *out) {
     REQUIRE(ctx && out, "null argument");
@@ -307,11 +307,33 @@ int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, ui
     return HYDIA_OK;
     API_END
 }
+// a handle over ciphertexts that stay in the CALLER's device memory (no copy): e.g. the all-gathered rotations of a rotation-split
+// loop A.  The memory must stay valid and unchanged while the handle or any operation enqueued on it is alive.
+int hydia_ct_view_device(hydia_ctx *ctx, void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs, double scale, hydia_ct **out) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && dev_ptr && out, "null argument");
+    REQUIRE(count >= 1 && (n_polys == 2 || n_polys == 3) && n_limbs >= 1 && (int)n_limbs <= ctx->cx.nQ, "bad ciphertext shape");
+    hydia_ct *h = new hydia_ct;
+    h->c.ctx = &ctx->cx;
+    h->c.d = static_cast<u64 *>(dev_ptr);
+    h->c.X = (int)count;
+    h->c.npoly = (int)n_polys;
+    h->c.nl = h->c.lstride = (int)n_limbs;
+    h->c.scale = scale;
+    h->c.view = true;
+    h->owner = ctx;
+    ctx->refs.fetch_add(1);
+    *out = h;
+    return HYDIA_OK;
+    API_END
+}
 void hydia_ct_free(hydia_ct *ct) {
     if (!ct) return;
     hydia_ctx *owner = ct->owner;
+    use_device(owner);  // the buffer goes back to the pool (or the context goes away) under the context's own GPU
     delete ct;
-    if (owner && --owner->live_handles == 0 && owner->destroy_requested) delete owner;
+    if (owner && owner->refs.fetch_sub(1) == 1) delete owner;
 }
 
 // ------------------------------------------------------------------ receiver
@@ -520,6 +542,26 @@ int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_
     API_END
 int hydia_rotate_query(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.rotate_query(query->c)) }
 int hydia_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.similarity(query->c)) }
+int hydia_rotate_query_range_into(hydia_ctx *ctx, const hydia_ct *query, uint32_t first, uint32_t count, void *dev_dst) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && query && dev_dst, "null argument");
+    ctx->cx.rotate_query_range(query->c, (int)first, (int)count, static_cast<u64 *>(dev_dst));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_rotate_query_range(hydia_ctx *ctx, const hydia_ct *query, uint32_t first, uint32_t count, hydia_ct **out) {
+    API_BEGIN
+    use_device(ctx);
+    REQUIRE(ctx && query && out && count >= 1, "bad argument");
+    Ct r(&ctx->cx, (int)count, 2, query->c.nl, query->c.scale);
+    ctx->cx.rotate_query_range(query->c, (int)first, (int)count, r.d);
+    *out = wrap(ctx, std::move(r));
+    return HYDIA_OK;
+    API_END
+}
+int hydia_compute_similarity_rotated(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.similarity_rot(query->c)) }
+int hydia_index_scenario_rotated(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.index_scenario_rot(query->c)) }
 int hydia_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.index_scenario(query->c)) }
 int hydia_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out) { SENDER_CALL(ctx->cx.membership_scenario(query->c)) }
 int hydia_chebyshev_compare(hydia_ctx *ctx, const hydia_ct *query, double delta, size_t sign_depth, hydia_ct **out) {

@@ -1,6 +1,7 @@
 // image_matching_amd/csrc/capi_internal.h — handle types and error plumbing shared by the extern "C" translation units
 // (capi.cpp: contexts, keys, ciphertexts, roles; group.cpp: the sharded multi-GPU sender).
 #pragma once
+#include <atomic>
 #include <string>
 
 #include "../../include/hydia.h"
@@ -12,8 +13,9 @@
 // their memory to is part of the context).
 struct hydia_ctx {
     hydia::Context cx;
-    long live_handles = 0;
-    bool destroy_requested = false;
+    // one reference of the context itself (dropped by hydia_ctx_destroy) + one per live hydia_ct: whoever drops the last one deletes
+    // the context.  Atomic: a binding's finaliser may free a handle on another thread than the one using the context.
+    std::atomic<long> refs{1};
     hydia_ctx(const hydia::Params &p, int dev) : cx(p, dev) {}
 };
 struct hydia_ct {
@@ -39,7 +41,7 @@ inline hydia_ct *wrap(hydia_ctx *owner, hydia::Ct &&c) {
     if (c.view || !c.compact()) h->c = c.ctx->clone(c);
     else h->c = std::move(c);
     h->owner = owner;
-    owner->live_handles++;
+    owner->refs.fetch_add(1);
     return h;
 }
 // HIP's current device is per host thread: every entry point that takes a context selects the context's GPU first, so one

@@ -803,17 +803,28 @@ Ct Context::rotate(const Ct &a, int rot) {
 // inner-product + ModDown + automorphism sequence.  Output: rot[0] = q, rot[i] = Rot_i(q).
 Ct Context::rotate_query(const Ct &qc) {
     if (qc.X != 1 || qc.npoly != 2 || !qc.compact()) throw std::runtime_error("hydia: query must be one 2-component ciphertext");
+    Ct rot(this, prm.dim, 2, qc.nl, qc.scale);
+    rotate_query_range(qc, 0, prm.dim, rot.d);
+    return rot;
+}
+// A contiguous range of the hoisted rotations (the whole loop A for first = 0, count = dim).  Every range repeats the ModUp of c1
+// (48 transforms against 32 per rotation), so R ranks that each take dim / R rotations do loop A's work once between them.
+void Context::rotate_query_range(const Ct &qc, int first, int count, u64 *out) {
+    if (qc.X != 1 || qc.npoly != 2 || !qc.compact()) throw std::runtime_error("hydia: query must be one 2-component ciphertext");
+    const int dim = prm.dim;
+    if (first < 0 || count < 0 || first + count > dim) throw std::runtime_error("hydia: rotation range outside 0 .. vector_dim");
+    if (count == 0) return;
+    const int nl = qc.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha;
+    const size_t ce = qc.ct_elems();
+    if (first == 0) HIP_CHECK(hipMemcpyAsync(out, qc.d, qc.bytes(), hipMemcpyDeviceToDevice, stream));
+    const int r0 = std::max(first, 1), nr = first + count - r0;
+    if (nr <= 0) return;
     build_rotptrs();
-    const int nl = qc.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, dim = prm.dim;
     u64 *dig = pool.get((size_t)nd * nE * N * sizeof(u64));
     modup_digits(qc.d + (size_t)nl * N, 0, 1, nl, dig);
-    Ct rot(this, dim, 2, nl, qc.scale);
-    HIP_CHECK(hipMemcpyAsync(rot.d, qc.d, qc.bytes(), hipMemcpyDeviceToDevice, stream));
-    if (dim > 1)
-        ks_apply(dig, 0, dim - 1, nl, d_rotptrs + 1, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + 1, d_rotginv + 1, 0, false,
-                 rot.d + rot.ct_elems(), rotptrs_packed ? nQ : 0);
+    ks_apply(dig, 0, nr, nl, d_rotptrs + r0, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + r0, d_rotginv + r0, 0, false,
+             out + (size_t)(r0 - first) * ce, rotptrs_packed ? nQ : 0);
     pool.put(dig);
-    return rot;
 }
 // computeSimilarity (sender_diag.cpp:12-33): all G blocks of the resident DB in one tensor-accumulate launch
 Ct Context::similarity(const Ct &qc) {
@@ -1158,14 +1169,29 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
 Ct Context::similarity_accumulate(const Ct &qc) {
     if (!d_db || db_cts == 0 || db_kind != 5) throw StateError("hydia: no database resident (diagonal packing)");
     if (qc.nl != nQ) throw StateError("hydia: query must be a fresh (level 0) ciphertext");
-    const int dim = prm.dim;
-    const int G = (int)(db_cts / dim);
     Ct rot = rotate_query(qc);
-    Ct acc(this, G, 3, nQ, qc.scale * delta);
+    return similarity_accumulate_rot(rot);
+}
+Ct Context::similarity_accumulate_rot(const Ct &rot) {
+    if (!d_db || db_cts == 0 || db_kind != 5) throw StateError("hydia: no database resident (diagonal packing)");
+    const int dim = prm.dim;
+    if (rot.X != dim || rot.npoly != 2 || rot.nl != nQ || !rot.compact())
+        throw StateError("hydia: rotations must be vector_dim fresh 2-component ciphertexts");
+    const int G = (int)(db_cts / dim);
+    Ct acc(this, G, 3, nQ, rot.scale * delta);
     timer_begin("hydia_tensor");
     hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
     timer_end("hydia_tensor");
     return acc;
+}
+Ct Context::similarity_rot(const Ct &rot) {
+    Ct acc = similarity_accumulate_rot(rot);
+    relin_rescale(acc);
+    return acc;
+}
+Ct Context::index_scenario_rot(const Ct &rot) {
+    Ct acc = similarity_accumulate_rot(rot);
+    return relin_compare_lanes(acc, 0.44, 10);
 }
 // indexScenario (sender_diag.cpp:52-63): loop A, loop B, then the per-block tails on the comparator lanes
 Ct Context::index_scenario(const Ct &qc) {

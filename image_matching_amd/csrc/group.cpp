@@ -26,6 +26,7 @@ struct hydia_group {
     std::vector<hydia_ctx *> shard;
     std::vector<size_t> blk_lo, blk_hi;  // block range of each shard of the resident database
     size_t n_vectors = 0, n_blocks = 0;
+    bool rot_split = true;  // loop A's rotations shared out over the active shards and exchanged (hydia_group_set_rotation_split)
 };
 
 namespace {
@@ -112,19 +113,61 @@ Ct gather_blocks(hydia_group *g, const std::vector<uint32_t> &act, std::vector<C
 }
 Ct compact(Context &cx, Ct &&c) { return (c.view || !c.compact()) ? cx.clone(c) : std::move(c); }
 
-template <class F>
-int sharded_blocks_call(hydia_group *g, const hydia_ct *query, hydia_ct **out, F per_shard) {
+// Loop A split over the active shards (SURVEY 8e option B): shard act[k] computes the contiguous rotation range
+// hydia_shard_blocks(dim, K, k) into its own slice of its full [dim][2][nQ][N] buffer, then fetches every other shard's slice by
+// peer copies enqueued on its OWN stream, so its mat-vec is ordered behind them.  Every shard ends up with exactly the rotations
+// rotate_query gives (each one is computed by the same kernels on the same operands wherever it runs).
+std::vector<Ct> split_rotations(hydia_group *g, const std::vector<uint32_t> &act, const std::vector<Ct> &qs) {
+    const uint32_t K = (uint32_t)act.size();
+    const int dim = g->shard[0]->cx.prm.dim;
+    std::vector<Ct> rot(g->shard.size());
+    std::vector<size_t> lo(K), hi(K);
+    for (uint32_t k = 0; k < K; k++) shard_blocks((size_t)dim, K, k, &lo[k], &hi[k]);
+    std::vector<uint32_t> idx(g->shard.size(), 0);
+    for (uint32_t k = 0; k < K; k++) idx[act[k]] = k;
+    on_shards(g, act, [&](uint32_t r) {
+        Context &cx = g->shard[r]->cx;
+        const uint32_t k = idx[r];
+        rot[r] = Ct(&cx, dim, 2, qs[r].nl, qs[r].scale);
+        cx.rotate_query_range(qs[r], (int)lo[k], (int)(hi[k] - lo[k]), rot[r].d + lo[k] * rot[r].ct_elems());
+        cx.sync_all();  // the slice is complete before any peer reads it
+    });
+    on_shards(g, act, [&](uint32_t r) {
+        Context &cx = g->shard[r]->cx;
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t s = act[k];
+            if (s == r || hi[k] == lo[k]) continue;
+            const size_t off = lo[k] * rot[r].ct_elems();
+            copy_between(cx, rot[r].d + off, g->shard[s]->cx, rot[s].d + off, (hi[k] - lo[k]) * rot[r].ct_elems() * sizeof(u64));
+        }
+        cx.sync();  // the sources may be released once every shard has its copies
+    });
+    return rot;
+}
+
+template <class F, class FR>
+int sharded_blocks_call(hydia_group *g, const hydia_ct *query, hydia_ct **out, F per_shard, FR per_shard_rot) {
     API_BEGIN
     REQUIRE(out, "null argument");
     check_query(g, query);
     const std::vector<uint32_t> act = active(g);
     std::vector<Ct> qs = broadcast_query(g, act, query->c);
     std::vector<Ct> res(g->shard.size());
-    on_shards(g, act, [&](uint32_t r) {
-        Context &cx = g->shard[r]->cx;
-        res[r] = compact(cx, per_shard(cx, qs[r]));
-        cx.sync_all();
-    });
+    if (g->rot_split && act.size() > 1) {
+        std::vector<Ct> rot = split_rotations(g, act, qs);
+        on_shards(g, act, [&](uint32_t r) {
+            Context &cx = g->shard[r]->cx;
+            res[r] = compact(cx, per_shard_rot(cx, rot[r]));
+            cx.sync_all();
+            rot[r] = Ct();  // back to this shard's pool, under its own device
+        });
+    } else {
+        on_shards(g, act, [&](uint32_t r) {
+            Context &cx = g->shard[r]->cx;
+            res[r] = compact(cx, per_shard(cx, qs[r]));
+            cx.sync_all();
+        });
+    }
     use_device(g->shard[0]);
     Ct all = gather_blocks(g, act, res);
     for (uint32_t r : act) {  // shard-local buffers go back to their own pools under their own device
@@ -268,11 +311,18 @@ int hydia_group_db_enroll(hydia_group *g, double *db, size_t n, const uint8_t se
     API_END
 }
 
+int hydia_group_set_rotation_split(hydia_group *g, int on) {
+    REQUIRE(g, "null argument");
+    g->rot_split = on != 0;
+    return HYDIA_OK;
+}
 int hydia_group_compute_similarity(hydia_group *g, const hydia_ct *query, hydia_ct **out) {
-    return sharded_blocks_call(g, query, out, [](Context &cx, const Ct &q) { return cx.similarity(q); });
+    return sharded_blocks_call(g, query, out, [](Context &cx, const Ct &q) { return cx.similarity(q); },
+                               [](Context &cx, const Ct &rot) { return cx.similarity_rot(rot); });
 }
 int hydia_group_index_scenario(hydia_group *g, const hydia_ct *query, hydia_ct **out) {
-    return sharded_blocks_call(g, query, out, [](Context &cx, const Ct &q) { return cx.index_scenario(q); });
+    return sharded_blocks_call(g, query, out, [](Context &cx, const Ct &q) { return cx.index_scenario(q); },
+                               [](Context &cx, const Ct &rot) { return cx.index_scenario_rot(rot); });
 }
 int hydia_group_membership_scenario(hydia_group *g, const hydia_ct *query, hydia_ct **out) {
     API_BEGIN
@@ -281,11 +331,15 @@ int hydia_group_membership_scenario(hydia_group *g, const hydia_ct *query, hydia
     const std::vector<uint32_t> act = active(g);
     std::vector<Ct> qs = broadcast_query(g, act, query->c);
     std::vector<Ct> part(g->shard.size());
+    std::vector<Ct> rot;
+    const bool split = g->rot_split && act.size() > 1;
+    if (split) rot = split_rotations(g, act, qs);
     on_shards(g, act, [&](uint32_t r) {
         Context &cx = g->shard[r]->cx;
-        Ct idx = cx.index_scenario(qs[r]);
+        Ct idx = split ? cx.index_scenario_rot(rot[r]) : cx.index_scenario(qs[r]);
         part[r] = cx.add_many(idx);  // EvalAddManyInPlace over this shard's blocks
         cx.sync_all();
+        if (split) rot[r] = Ct();
     });
     Context &c0 = g->shard[0]->cx;
     use_device(g->shard[0]);

@@ -253,7 +253,14 @@ struct Context : HostParams {
 
     // ---- HyDia sender (src/sender/sender_diag.cpp)
     Ct rotate_query(const Ct &q);                   // -> [dim][2][nQ][N]
+    // rotations first .. first+count-1 of the query (rotation 0 = the query itself) into out [count][2][nQ][N]: one rank's share of
+    // loop A when the rotations are split over the GPUs of a node and all-gathered (SURVEY 8e option B)
+    void rotate_query_range(const Ct &q, int first, int count, u64 *out);
     Ct similarity(const Ct &q);                     // -> [G][2][nQ-1][N]
+    // the same scenarios on rotations supplied by the caller ([dim][2][nQ][N], as rotate_query returns them)
+    Ct similarity_accumulate_rot(const Ct &rot);
+    Ct similarity_rot(const Ct &rot);
+    Ct index_scenario_rot(const Ct &rot);
     Ct chebyshev_compare(const Ct &x, double delta, int sign_depth);
     Ct index_scenario(const Ct &q);
     Ct membership_scenario(const Ct &q);

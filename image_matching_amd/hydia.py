@@ -81,6 +81,12 @@ def load_library():
         "hydia_ct_device_ptr": (i32, [vp, pp, C.POINTER(sz)]),
         "hydia_ct_from_device": (i32, [vp, vp, u32, u32, u32, dbl, pp]),
         "hydia_ct_copy_to_device": (i32, [vp, vp, vp]),
+        "hydia_ct_view_device": (i32, [vp, vp, u32, u32, u32, dbl, pp]),
+        "hydia_rotate_query_range_into": (i32, [vp, vp, u32, u32, vp]),
+        "hydia_rotate_query_range": (i32, [vp, vp, u32, u32, pp]),
+        "hydia_compute_similarity_rotated": (i32, [vp, vp, pp]),
+        "hydia_index_scenario_rotated": (i32, [vp, vp, pp]),
+        "hydia_group_set_rotation_split": (i32, [vp, i32]),
         "hydia_ct_free": (None, [vp]),
         "hydia_encrypt_query": (i32, [vp, vp, vp, u64, pp]),
         "hydia_encrypt": (i32, [vp, vp, u32, vp, u64, pp]),
@@ -353,6 +359,15 @@ class Context:
         _chk(self.L.hydia_ct_from_device(self.h, C.c_void_p(ptr), count, n_polys, n_limbs, scale, C.byref(h)))
         return Ciphertext(self, h)
 
+    def ct_view_device(self, ptr, count, n_polys, n_limbs, scale, keepalive=None):
+        """A handle over ciphertexts that stay in the caller's device memory (no copy).  `keepalive` (e.g. the torch tensor that owns
+        the memory) is referenced by the handle."""
+        h = C.c_void_p()
+        _chk(self.L.hydia_ct_view_device(self.h, C.c_void_p(ptr), count, n_polys, n_limbs, scale, C.byref(h)))
+        ct = Ciphertext(self, h)
+        ct._keepalive = keepalive
+        return ct
+
     def _out(self, fn, *args):
         h = C.c_void_p()
         _chk(fn(self.h, *args, C.byref(h)))
@@ -527,6 +542,21 @@ class DiagonalSender:
 
     def indexScenario(self, query_cipher):
         return self.cc._out(self.cc.L.hydia_index_scenario, query_cipher.h)
+
+    # ---- loop A split over the GPUs of a node (sender_diag.cpp:23-26 cut into ranges; image_matching_amd.sharding)
+    def rotateQueryRange(self, query_cipher, first, count):
+        """rotations first .. first+count-1 of the query (0 = the query itself) as a batch of `count` ciphertexts"""
+        return self.cc._out(self.cc.L.hydia_rotate_query_range, query_cipher.h, first, count)
+
+    def rotateQueryRangeInto(self, query_cipher, first, count, dev_ptr):
+        """rotations first .. first+count-1 of the query (0 = the query itself) into device memory [count][2][nQ][N]"""
+        _chk(self.cc.L.hydia_rotate_query_range_into(self.cc.h, query_cipher.h, first, count, C.c_void_p(dev_ptr)))
+
+    def computeSimilarityRotated(self, rotations):
+        return self.cc._out(self.cc.L.hydia_compute_similarity_rotated, rotations.h)
+
+    def indexScenarioRotated(self, rotations):
+        return self.cc._out(self.cc.L.hydia_index_scenario_rotated, rotations.h)
 
 
 # ---- HERS, approach 4 (SURVEY 8f-4): include/enroller_hers.h:16-37, include/receiver_hers.h:9-28, include/sender_hers.h:9-44

@@ -59,6 +59,10 @@ class ShardGroup:
     def keygen(self, seed=None):
         _h._chk(self.L.hydia_group_keygen(self.g, _h._p(_h._seed(seed))))
 
+    def set_rotation_split(self, on):
+        """loop A shared out over the active shards and exchanged (default) or recomputed by every shard"""
+        _h._chk(self.L.hydia_group_set_rotation_split(self.g, 1 if on else 0))
+
     def shard_range(self, r):
         a, b = C.c_size_t(), C.c_size_t()
         _h._chk(self.L.hydia_group_shard_range(self.g, r, C.byref(a), C.byref(b)))
@@ -135,10 +139,12 @@ class DistDiagonalSender:
     Every rank calls the scenario methods; rank 0 passes the query ciphertext (other ranks pass None) and receives the result
     (other ranks get None).  make_sender(cc, n_local) builds the rank-local sender (default DiagonalSender)."""
 
-    def __init__(self, cc, n_total, dist, rank, world, staging="device", make_sender=None):
+    def __init__(self, cc, n_total, dist, rank, world, staging="device", make_sender=None, rotation_split=True):
         import torch
         self.torch = torch
         self.cc, self.n_total, self.dist, self.rank, self.world, self.staging = cc, n_total, dist, rank, world, staging
+        if world > 16:  # the membership reduction adds residues below 2^60 as 64-bit integers: exact for at most 16 terms
+            raise ValueError("DistDiagonalSender supports at most 16 ranks (integer sum of partial membership ciphertexts)")
         self.G = -(-n_total // cc.slots)
         self.ranges = [shard_blocks(self.G, world, r) for r in range(world)]
         self.lo, self.hi = self.ranges[rank]
@@ -146,6 +152,14 @@ class DistDiagonalSender:
         first, last = shard_vectors(n_total, cc.slots, world, rank)
         self.local = (make_sender or _h.DiagonalSender)(cc, last - first) if self.hi > self.lo else None
         self._bufs = {}
+        # Loop A: option A = every rank computes all 511 rotations itself; option B (rotation_split) = rank k of the K
+        # ranks that hold blocks computes the contiguous range shard_blocks(dim, K, k) and the ranges are all-gathered (3 GiB in all
+        # over xGMI), so the node does loop A's work once instead of once per GPU.  Same ciphertexts either way.
+        self.rotation_split = bool(rotation_split) and world > 1
+        self.active = [r for r, (lo, hi) in enumerate(self.ranges) if hi > lo]
+        K = len(self.active)
+        self.rot_ranges = {r: shard_blocks(cc.dim, K, k) for k, r in enumerate(self.active)}
+        self.rot_even = K > 0 and cc.dim % K == 0 and K == world  # every rank holds blocks and the ranges are equal: in-place all_gather
 
     # ---- buffers: int64 tensors that mirror [count][poly][limb][N] residues
     def _buf(self, key, n):
@@ -217,7 +231,51 @@ class DistDiagonalSender:
         parts = [recv[r][:(hi - lo) * per] for r, (lo, hi) in enumerate(self.ranges) if hi > lo]
         return self._to_ct(self.torch.cat(parts), self.G, npoly, nl, scale)
 
+    def _gathered_rotations(self, q):
+        """option B: this rank's range of loop A into its slice of the full [dim][2][nQ][N] buffer, all_gather of the slices, and a
+        ciphertext handle over the buffer (no copy).  Ranks without blocks take part in the collective with an empty range."""
+        cc, dim = self.cc, self.cc.dim
+        per = 2 * cc.nQ * cc.N
+        full = self._buf("rot", dim * per)
+        lo, hi = self.rot_ranges.get(self.rank, (0, 0))
+        scale = self._bufs["q_scale"]
+        if self.staging == "device":
+            if hi > lo:
+                self.local.rotateQueryRangeInto(q, lo, hi - lo, full.data_ptr() + lo * per * 8)
+            cc.sync()  # the slice is written on the library's stream; the collective runs on torch's
+            if self.rot_even:
+                self.dist.all_gather_into_tensor(full, full[lo * per:hi * per])
+            else:
+                cnt = max(h - l for l, h in self.rot_ranges.values())
+                send = self._buf("rot_send", cnt * per)
+                if hi > lo:
+                    send[:(hi - lo) * per].copy_(full[lo * per:hi * per])
+                recv = [self._buf("rot_recv%d" % r, cnt * per) for r in range(self.world)]
+                self.dist.all_gather(recv, send)
+                for r, (l, h) in self.rot_ranges.items():
+                    if r != self.rank and h > l:
+                        full[l * per:h * per].copy_(recv[r][:(h - l) * per])
+            self.torch.cuda.current_stream().synchronize()  # the library reads `full` from its own stream
+            return cc.ct_view_device(full.data_ptr(), dim, 2, cc.nQ, scale, keepalive=full) if self.local is not None else None
+        # host staging (gloo): the same steps through host tensors
+        cnt = max([h - l for l, h in self.rot_ranges.values()] + [1])
+        send = self._buf("rot_send", cnt * per)
+        if hi > lo:
+            a = self.local.rotateQueryRange(q, lo, hi - lo).export().reshape(-1).view(np.int64)
+            send[:a.size] = self.torch.from_numpy(a)
+        recv = [self._buf("rot_recv%d" % r, cnt * per) for r in range(self.world)]
+        self.dist.all_gather(recv, send)
+        if self.local is None:
+            return None
+        for r, (l, h) in self.rot_ranges.items():
+            if h > l:
+                full[l * per:h * per] = recv[r][:(h - l) * per]
+        return cc.import_ct(full.numpy().view(np.uint64).reshape(dim, 2, cc.nQ, cc.N), scale)
+
     def _local(self, fn_name, q):
+        if self.rotation_split:
+            rot = self._gathered_rotations(q)
+            return getattr(self.local, fn_name + "Rotated")(rot) if self.local is not None else None
         return getattr(self.local, fn_name)(q) if self.local is not None else None
 
     def computeSimilarity(self, query_cipher):

@@ -114,6 +114,10 @@ int hydia_ct_device_ptr(const hydia_ct *ct, void **ptr, size_t *bytes);
 int hydia_ct_copy_to_device(hydia_ctx *ctx, const hydia_ct *ct, void *dev_dst);
 int hydia_ct_from_device(hydia_ctx *ctx, const void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs,
                          double scale, hydia_ct **out); /* copies */
+/* a handle over ciphertexts that STAY in the caller's device memory (no copy): the all-gathered rotations of a rotation-split loop A.
+ * The memory must stay valid and unchanged while the handle, or work enqueued on it, is alive */
+int hydia_ct_view_device(hydia_ctx *ctx, void *dev_ptr, uint32_t count, uint32_t n_polys, uint32_t n_limbs, double scale,
+                         hydia_ct **out);
 void hydia_ct_free(hydia_ct *ct);
 
 /* ---- receiver: DiagonalReceiver / HersReceiver ---- */
@@ -164,6 +168,14 @@ int hydia_rotate_query(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
 int hydia_compute_similarity(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
 /* Sender::indexScenario (:52-63) */
 int hydia_index_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
+/* Loop A split over the GPUs of a node (the `#pragma omp parallel for` over i of src/sender/sender_diag.cpp:23-26, cut into ranges):
+ * rotations first .. first+count-1 of the query (rotation 0 = the query itself) written to dev_dst [count][2][n_q][N]; the ranges of
+ * all ranks, all-gathered into one [vector_dim][2][n_q][N] buffer, are what hydia_rotate_query returns — and what the *_rotated
+ * forms of computeSimilarity / indexScenario take instead of the query (a hydia_ct_view_device over the gathered buffer) */
+int hydia_rotate_query_range(hydia_ctx *ctx, const hydia_ct *query, uint32_t first, uint32_t count, hydia_ct **out);
+int hydia_rotate_query_range_into(hydia_ctx *ctx, const hydia_ct *query, uint32_t first, uint32_t count, void *dev_dst);
+int hydia_compute_similarity_rotated(hydia_ctx *ctx, const hydia_ct *rotations, hydia_ct **out);
+int hydia_index_scenario_rotated(hydia_ctx *ctx, const hydia_ct *rotations, hydia_ct **out);
 /* Sender::membershipScenario (:35-50) */
 int hydia_membership_scenario(hydia_ctx *ctx, const hydia_ct *query, hydia_ct **out);
 /* OpenFHEWrapper::chebyshevCompare (src/openFHE_wrapper.cpp:143-185) on every ciphertext of the batch */
@@ -201,6 +213,11 @@ int hydia_group_keygen(hydia_group *g, const uint8_t seed[32]);
  * hydia_group_shard_range */
 int hydia_group_db_enroll(hydia_group *g, double *db /* n x vector_dim */, size_t n, const uint8_t seed[32]);
 int hydia_group_shard_range(const hydia_group *g, uint32_t shard, size_t *first_vector, size_t *n_vectors);
+/* How loop A (the 511 hoisted rotations) is shared: 0 = every shard computes all of them itself (nothing exchanged before the
+ * mat-vec); 1 = shard k of the K active ones computes the contiguous range hydia_shard_blocks(vector_dim, K, k) and the ranges are
+ * exchanged by peer copies (SURVEY 8e option B: loop A's work is done once per node instead of once per GPU).  Default 1.
+ * Results are bit-identical either way. */
+int hydia_group_set_rotation_split(hydia_group *g, int on);
 /* Sender::computeSimilarity / indexScenario / membershipScenario over all shards; query and *out live in shard 0 */
 int hydia_group_compute_similarity(hydia_group *g, const hydia_ct *query, hydia_ct **out);
 int hydia_group_index_scenario(hydia_group *g, const hydia_ct *query, hydia_ct **out);

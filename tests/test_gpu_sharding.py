@@ -49,7 +49,7 @@ def single_context_results(im, prm, n, db, planted, query, kseed=31, dseed=8, qs
     return out
 
 
-def check_group(im, prm, devices, n, db, planted, query, want):
+def check_group(im, prm, devices, n, db, planted, query, want, splits=(True, False)):
     grp = im.ShardGroup(devices, prm)
     grp.keygen(31)
     b = db.copy()
@@ -69,14 +69,18 @@ def check_group(im, prm, devices, n, db, planted, query, want):
     sender, receiver = im.ShardedDiagonalSender(grp, n), im.DiagonalReceiver(cc0, n)
     q = receiver.encryptQuery(query, seed=2, nonce=9)
     assert np.array_equal(q.export(), want["q"])
-    assert np.array_equal(sender.computeSimilarity(q).export(), want["sim"])
-    idx = sender.indexScenario(q)
-    assert np.array_equal(idx.export(), want["idx"])          # global block order
-    assert receiver.decryptIndex(idx) == want["found"]         # global indices
-    mem = sender.membershipScenario(q)
-    assert np.array_equal(mem.export(), want["mem"])           # add-many -> integer sum -> mod q -> EvalSum
-    assert receiver.decryptMembership(mem) == want["member"] and (want["member"] or not planted)
-    del q, idx, mem
+    # loop A shared out over the shards and exchanged (default, SURVEY 8e option B), then recomputed by every shard (option A)
+    for split in splits:
+        grp.set_rotation_split(split)
+        assert np.array_equal(sender.computeSimilarity(q).export(), want["sim"])
+        idx = sender.indexScenario(q)
+        assert np.array_equal(idx.export(), want["idx"])          # global block order
+        assert receiver.decryptIndex(idx) == want["found"]         # global indices
+        mem = sender.membershipScenario(q)
+        assert np.array_equal(mem.export(), want["mem"])           # add-many -> integer sum -> mod q -> EvalSum
+        assert receiver.decryptMembership(mem) == want["member"] and (want["member"] or not planted)
+        del idx, mem
+    del q
     grp.close()
 
 
@@ -233,6 +237,22 @@ class ThreadDist:
         self.slots[self.local.rank] = dict(t=t)
         self._run(lambda r: [t.add_(self.slots[k]["t"]) for k in range(self.world) if k != dst] if r == dst else None)
 
+    def all_gather_into_tensor(self, out, inp):
+        m = inp.numel()
+        self.slots[self.local.rank] = dict(t=inp)
+
+        def fn(r):
+            for k in range(self.world):
+                if k != r:
+                    out[k * m:(k + 1) * m].copy_(self.slots[k]["t"], non_blocking=True)
+            if out[r * m:(r + 1) * m].data_ptr() != inp.data_ptr():
+                out[r * m:(r + 1) * m].copy_(inp, non_blocking=True)
+        self._run(fn)
+
+    def all_gather(self, recv, t):
+        self.slots[self.local.rank] = dict(t=t)
+        self._run(lambda r: [recv[k].copy_(self.slots[k]["t"], non_blocking=True) for k in range(self.world)])
+
     def broadcast_object_list(self, objs, src):
         r = self.local.rank
         if r == src:
@@ -242,7 +262,7 @@ class ThreadDist:
         self.bar.wait()
 
 
-n, world = int(sys.argv[2]), 3
+n, world, split = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "1"
 prm = im.default_params(log_n=11, vector_dim=64)
 planted = sorted({0, min(1024, n - 1), n - 1})
 db = make_db(n, 64, planted, n)
@@ -259,7 +279,7 @@ def rank_main(rank):
             cc.keygen(31)
             enr = im.DistDiagonalEnroller(cc, n, rank, world)
             enr.serializeDB(np.ascontiguousarray(db[enr.first:enr.last]), seed=8)
-            sender = im.DistDiagonalSender(cc, n, td, rank, world, staging="device")
+            sender = im.DistDiagonalSender(cc, n, td, rank, world, staging="device", rotation_split=split)
             receiver = im.DiagonalReceiver(cc, n)
             for rep in range(2):
                 q = receiver.encryptQuery(np.ones(64), seed=2, nonce=9) if rank == 0 else None
@@ -289,18 +309,43 @@ print("thread-dist ok")
 '''
 
 
-@pytest.mark.parametrize("n", [5000, 1000])
-def test_dist_sender_device_staging_under_async_collectives(tmp_path, n):
+@pytest.mark.parametrize("n,world,split", [(5000, 3, True), (1000, 3, True), (5000, 2, True), (5000, 3, False)])
+def test_dist_sender_device_staging_under_async_collectives(tmp_path, n, world, split):
     """DistDiagonalSender with staging="device" and world = 3 (n = 5000: uneven shards of 2 + 2 + 1 blocks of 1024 vectors; n = 1000: one
     block, ranks 1 and 2 own nothing): three threads, three
     contexts on GPU 0, collectives with NCCL's asynchronous stream semantics (ThreadDist in the script above: RCCL itself refuses two
     ranks on one GPU) that complete a few milliseconds LATE.  Rank 0's gathered similarity / index batches and its reduced membership
-    ciphertext equal the single-context ones bit for bit, twice in a row (buffer reuse).  Runs in its own process (torch's HIP runtime
+    ciphertext equal the single-context ones bit for bit, twice in a row (buffer reuse).  split = loop A's rotations shared out over
+    the ranks and all-gathered (SURVEY 8e option B): world 3 takes the padded all_gather (64 rotations do not divide by 3), world 2 the
+    in-place all_gather_into_tensor straight into the rotation buffer the mat-vec reads.  Runs in its own process (torch's HIP runtime
     next to the library's, started before anything forks)."""
     script = tmp_path / "thread_dist.py"
     script.write_text(THREAD_DIST_SCRIPT)
-    r = subprocess.run([sys.executable, str(script), ROOT, str(n)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(n), str(world), "1" if split else "0"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "thread-dist ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_rotation_ranges_reassemble_loop_a(im):
+    """hydia_rotate_query_range over any partition of 0 .. vector_dim-1 gives exactly the ciphertexts of hydia_rotate_query (full ring),
+    and the *_rotated scenarios on them the ciphertexts of the plain scenarios — what the rotation-split multi-GPU sender relies on."""
+    n = 20000
+    cc = im.Context()
+    cc.keygen(31)
+    db = make_db(n, 512, [7, n - 1], 3)
+    im.DiagonalEnroller(cc, n).serializeDB(db, seed=8)
+    q = im.DiagonalReceiver(cc, n).encryptQuery(np.ones(512), seed=2, nonce=9)
+    s = im.DiagonalSender(cc, n)
+    full = s.rotateQuery(q)
+    want = full.export()
+    for parts in ([(0, 512)], [(0, 1), (1, 511)], [(0, 171), (171, 171), (342, 170)], [(64 * k, 64) for k in range(8)]):
+        got = np.concatenate([s.rotateQueryRange(q, lo, cnt).export() for lo, cnt in parts])
+        assert np.array_equal(got, want), parts
+    assert np.array_equal(s.indexScenarioRotated(full).export(), s.indexScenario(q).export())
+    assert np.array_equal(s.computeSimilarityRotated(full).export(), s.computeSimilarity(q).export())
+    with pytest.raises(im.HydiaError):
+        s.rotateQueryRange(q, 500, 13)  # past vector_dim
+    del full, q
+    cc.close()
 
 
 def test_rekey_refreshes_loop_a_keys(im):
@@ -426,8 +471,8 @@ def test_db_save_load_round_trip(im, tmp_path):
 
 
 def test_shard_group_full_size_2p20(im):
-    """BASELINE config 5's database (2^20 vectors, 64 blocks, 148 GiB resident) through the sharded sender with two shards on the one
-    GPU: index batch (global block order), decrypted global indices and the membership ciphertext equal the single-context run's."""
+    """BASELINE config 5's database (2^20 vectors, 64 blocks, 148 GiB resident) through the sharded sender in config 5's own shape,
+    EIGHT shards of 8 blocks (all on the one GPU; loop A's rotations shared out over the shards and exchanged): index batch (global block order), decrypted global indices and the membership ciphertext equal the single-context run's."""
     n = 1 << 20
     planted = [0, 12345, n // 2 + 3, n - 1]
     rng = np.random.default_rng(2020)
@@ -448,11 +493,11 @@ def test_shard_group_full_size_2p20(im):
     want_idx, want_mem, want_q = idx.export(), sender.membershipScenario(q).export(), q.export()
     del q, idx
     cc.close()
-    grp = im.ShardGroup([0, 0], prm)
+    grp = im.ShardGroup([0] * 8, prm)  # config 5's own shape: 8 shards of 8 blocks (here all on the one GPU; keys resident once)
     grp.keygen(31)
     im.ShardedDiagonalEnroller(grp, n).serializeDB(db, seed=8)
     del db
-    assert grp.shard_range(0) == (0, n // 2) and grp.shard_range(1) == (n // 2, n // 2)
+    assert grp.shard_range(0) == (0, n // 8) and grp.shard_range(7) == (7 * (n // 8), n // 8)
     gr, gs = im.DiagonalReceiver(grp.ctx0, n), im.ShardedDiagonalSender(grp, n)
     gq = gr.encryptQuery(query, seed=2, nonce=9)
     assert np.array_equal(gq.export(), want_q)

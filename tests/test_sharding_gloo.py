@@ -59,6 +59,11 @@ def block_result(g, kind):
     return np.stack([rng.integers(0, Q[l], size=(2, N), dtype=np.uint64) for l in range(2)], axis=1)
 
 
+def fake_rotation(query, i):
+    """stand-in for rotation i of the query: a deterministic function of (query, i); rotation 0 is the query itself"""
+    return query[0] if i == 0 else (query[0] * np.uint64(2 * i + 1) + np.uint64(i)) % np.uint64(Q[0])
+
+
 class FakeSender:
     def __init__(self, lo, hi, query_check):
         self.lo, self.hi, self.query_check = lo, hi, query_check
@@ -72,6 +77,22 @@ class FakeSender:
 
     def indexScenario(self, q):
         return self._run(q, 2)
+
+    # rotation-split loop A: a rank computes a range, the scenarios take the gathered set
+    def rotateQueryRange(self, q, first, count):
+        assert np.array_equal(q.export(), self.query_check), "every rank must receive rank 0's query"
+        return FakeCt(np.stack([fake_rotation(q.export(), i) for i in range(first, first + count)]), q.scale)
+
+    def _run_rot(self, rot, kind):
+        want = np.stack([fake_rotation(self.query_check, i) for i in range(FakeContext.dim)])
+        assert np.array_equal(rot.export(), want), "the gathered rotations must be the full set in rotation order"
+        return FakeCt(np.stack([block_result(g, kind) for g in range(self.lo, self.hi)]), 2.0 ** 45)
+
+    def computeSimilarityRotated(self, rot):
+        return self._run_rot(rot, 1)
+
+    def indexScenarioRotated(self, rot):
+        return self._run_rot(rot, 2)
 
 
 def test_shard_blocks_partition():
@@ -94,7 +115,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, G, out):
+def _worker(rank, world, port, G, split, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -103,7 +124,11 @@ def _worker(rank, world, port, G, out):
     n_total = G * SLOTS - 5  # ragged last block
     lo, hi = sharding.shard_blocks(G, world, rank)
     sender = sharding.DistDiagonalSender(cc, n_total, dist, rank, world, staging="host",
-                                         make_sender=lambda c, n: FakeSender(lo, hi, query))
+                                         make_sender=lambda c, n: FakeSender(lo, hi, query), rotation_split=split)
+    assert sender.rotation_split == split
+    if split:  # the ranks that hold blocks share the rotations 0 .. dim-1 between them, in rank order
+        ranges = [sender.rot_ranges[r] for r in sender.active]
+        assert ranges[0][0] == 0 and ranges[-1][1] == cc.dim and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     assert (sender.lo, sender.hi) == (lo, hi) and (sender.local is None) == (hi == lo)
     q = FakeCt(query, 2.0 ** 45) if rank == 0 else None
     for _ in range(2):  # second call reuses the cached buffers / metadata
@@ -125,12 +150,14 @@ def _worker(rank, world, port, G, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,G", [(2, 5), (2, 1), (3, 8)])
-def test_dist_sender_host_logic(world, G):
+@pytest.mark.parametrize("world,G,split", [(2, 5, False), (2, 1, True), (3, 8, True), (2, 4, True)])
+def test_dist_sender_host_logic(world, G, split):
+    """split = loop A's rotations shared out over the ranks that hold blocks and all-gathered (SURVEY 8e option B); (2, 1): one of the
+    two ranks holds no block and joins the collectives with an empty range"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, G, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, G, split, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
