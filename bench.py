@@ -3,10 +3,15 @@
 
 A "step" is ONE query through DiagonalSender::indexScenario (/root/reference/src/sender/sender_diag.cpp:52-63: 511 hoisted
 rotations, per block 512 tensor products + 1 relinearise + 1 rescale, degree-59 Chebyshev o f4 comparator) over the
-encrypted database resident in HBM.  For N > 1 the database is sharded by 16384-vector row-blocks over the ranks and the step
-runs through image_matching_amd.sharding.DistDiagonalSender — the same class the tests pin bit-exactly against one context:
-rank 0's query is broadcast, every rank runs an independent mat-vec + comparator on its own blocks (no data-path collective),
-and the result ciphertexts are gathered over RCCL to rank 0 in global block order.  Per-GPU work is fixed as N grows ("weak").
+encrypted database resident in HBM.
+  N = 1   the 2^20-vector database (64 blocks, 148 GiB resident) on one GPU — the configuration BASELINE.json quotes its target on.
+  N > 1   STRONG scaling by default: the SAME 2^20-vector database sharded by 16384-vector row-blocks over the N ranks
+          (BASELINE config 5 at N = 8: 8 blocks per GPU; `--total-log2n 17` at N = 4 is config 4), through
+          image_matching_amd.sharding.DistDiagonalSender — the class the tests pin bit-exactly against one context: rank 0's query
+          is broadcast, loop A's rotations are either shared out over the ranks and all-gathered over xGMI (SURVEY 8e option B) or
+          recomputed by every rank (option A) — whichever the warm-up measures faster on this node —, every rank runs an independent
+          mat-vec + comparator on its own blocks, and the result ciphertexts are gathered over RCCL to rank 0 in global block order.
+          `--weak` keeps 2^log2n vectors PER GPU instead; its figure also rides in config.secondary of a default run.
 Data is synthetic with the distribution of the reference's tools/gen_dataset.sh (query = ones, random rows in [-99,99], planted
 matches in {1,2,3}); the database is REAL ciphertexts produced by the on-GPU enroller, and after the timed region rank 0
 decrypts the gathered index result and checks it against the planted matches (global indices).
@@ -17,6 +22,7 @@ decrypts the gathered index result and checks it against the planted matches (gl
 """
 import argparse
 import json
+import math
 import os
 import shutil
 import subprocess
@@ -66,6 +72,27 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_share():
+    """CPUs this job may really use: the scheduler affinity, capped by the cgroup CPU quota when there is one (a GPU box shows
+    every hardware thread of its host but grants a share of them)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(math.ceil(quota))))
+    return cores, aff, quota
+
+
 def cpu_baseline():
     """Time the CPU oracle (this repository's restatement of the reference algorithm — OpenFHE itself is absent, kind "port")
     on this host's cores, the way BASELINE.md §2 prescribes: the same indexScenario at G = 1 and G = 3 blocks in RAM, the
@@ -74,6 +101,9 @@ def cpu_baseline():
     disk like the reference's timed loop (sender_diag.cpp:87-91).  Only this leg touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    # all host cores this job has (BASELINE.md section 2): the affinity mask, capped by the cgroup quota — NOT the test helper's cap of 16
+    cores, aff, quota = cpu_share()
+    O.lib().hyo_set_num_threads(cores)
     P = O.Params()
     K = O.Keys(P, SEED)
     Or = O.Oracle(P, K)
@@ -116,7 +146,8 @@ def cpu_baseline():
     cores = int(O.lib().hyo_num_threads())
     return {
         "value": (1 << 20) / t_2p20, "unit": "vectors/s", "cores": cores, "kind": "port",
-        "cpu_model": cpu_model(), "omp_max_threads": cores, "host_logical_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(), "omp_max_threads": cores, "host_logical_cpus": os.cpu_count(), "affinity_cpus": aff,
+        "cgroup_cpu_quota": quota,
         "sample": "oracle indexScenario at N=2^15 timed at G=1 (%.2f s, of which the 511 hoisted rotations %.2f s) and G=3 (%.2f s) "
                   "blocks of 16384 vectors, DB in RAM: marginal %.3f s per block; value = 2^20 / (t_G1 + 63 x marginal) = linear "
                   "extrapolation to the 64 blocks of the GPU workload (%.1f s per query); results %s"
@@ -132,9 +163,17 @@ def cpu_baseline():
 
 
 def git_head():
+    """commit the numbers belong to: git when there is a checkout, else the VERSION file __graft_entry__.build() leaves in the tree
+    (the GPU box receives a snapshot without .git)"""
     try:
-        return subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        h = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        if h:
+            return h
     except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "image_matching_amd", "VERSION")).read().strip()
+    except OSError:
         return ""
 
 
@@ -143,9 +182,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log2n", type=int, default=20, help="log2 of DB vectors PER GPU (default 2^20 = 148 GiB resident, 192 GiB unpacked)")
+    ap.add_argument("--log2n", type=int, default=20,
+                    help="log2 of the DB vectors (one GPU: of that GPU; N > 1: of the TOTAL database unless --weak)")
     ap.add_argument("--total-log2n", type=int, default=None,
-                    help="strong-scaling variant (BASELINE configs 4/5): log2 of the TOTAL DB vectors, split over the ranks by blocks")
+                    help="N > 1: log2 of the TOTAL DB vectors, split over the ranks by blocks (default 20 = BASELINE config 5; 17 = config 4)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: 2^log2n vectors PER GPU (weak scaling) instead of a fixed total")
+    ap.add_argument("--loop-a", choices=["auto", "split", "replicated"], default="auto",
+                    help="N > 1: loop A's 511 rotations shared out over the ranks and all-gathered (split), recomputed by every rank "
+                         "(replicated), or whichever the warm-up measures faster (auto)")
+    ap.add_argument("--no-secondary-weak", action="store_true", help="N > 1: skip the weak-scaling figure of config.secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-db", action="store_true", help="fill the DB with random residues instead of enrolling")
     args = ap.parse_args()
@@ -177,8 +222,13 @@ def main():
 
     import image_matching_amd as im
     cc = im.Context(im.default_params(), 0 if rehearse else local_rank)
-    strong = args.total_log2n is not None
-    n_total = (1 << args.total_log2n) if strong else world * (1 << args.log2n)
+    strong = world > 1 and not args.weak
+    if world == 1:
+        n_total = 1 << (args.total_log2n if args.total_log2n is not None else args.log2n)
+    elif strong:
+        n_total = 1 << (args.total_log2n if args.total_log2n is not None else args.log2n)
+    else:
+        n_total = world * (1 << args.log2n)
     dim, S = cc.dim, cc.slots
     first, last = im.shard_vectors(n_total, S, world, rank)
     n_local = last - first
@@ -221,19 +271,41 @@ def main():
         dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
         torch.cuda.synchronize()
     res = None
+
+    def timed(snd, query, k):
+        """k steps bracketed by fences; the MAX over ranks of the wall time"""
+        nonlocal res
+        fence()
+        t_0 = time.time()
+        for _ in range(k):
+            res = snd.indexScenario(query)
+        fence()
+        dt = time.time() - t_0
+        if multi:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # loop A across ranks (untimed set-up): both forms give the same ciphertexts; which is faster depends on what the node's xGMI
+    # all-gather of the 3 GiB of rotated queries costs against recomputing them — measured here, on this node, then fixed
+    loop_a = None
+    if multi and world > 1:
+        loop_a = {"mode": args.loop_a}
+        if args.loop_a == "auto":
+            trial = {}
+            for mode in ("split", "replicated"):
+                sender.rotation_split = mode == "split"
+                timed(sender, qc, 1)  # buffers, channels
+                trial[mode] = timed(sender, qc, 2) / 2 * 1e3
+            loop_a.update({"ms_per_step_split": round(trial["split"], 3), "ms_per_step_replicated": round(trial["replicated"], 3)})
+            loop_a["mode"] = "split" if trial["split"] <= trial["replicated"] else "replicated"
+        sender.rotation_split = loop_a["mode"] == "split"
     for _ in range(args.warmup):
         res = sender.indexScenario(qc)
     fence()
     cc.kernel_time_reset()
-    t0 = time.time()
-    for _ in range(args.steps):
-        res = sender.indexScenario(qc)
-    fence()
-    elapsed = time.time() - t0
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(sender, qc, args.steps)
 
     ms_tensor, launches = cc.kernel_time("hydia_tensor")
     # secondary figure of SURVEY 8d (outside the timed region): computeSimilarity alone = loop A + loop B + relin + rescale
@@ -259,6 +331,35 @@ def main():
     if not args.random_db and rank == 0 and res is not None:
         correct = receiver.decryptIndex(res) == planted and len(res) == -(-n_total // S)
 
+    db_resident_bytes = cc.db_stats()[2]  # of the database that was timed (the optional weak figure below re-enrols)
+    if multi:  # every rank takes the same branches below (collectives inside)
+        flag = [bool(correct)]
+        dist.broadcast_object_list(flag, src=0)
+        correct = flag[0]
+    # N > 1, default run: the weak-scaling figure (2^log2n vectors PER GPU) beside the strong one, outside the timed region
+    weak = None
+    if multi and world > 1 and strong and not args.no_secondary_weak and not args.random_db and correct:
+        try:
+            n_w = world * (1 << args.log2n)
+            f_w, l_w = im.shard_vectors(n_w, S, world, rank)
+            planted_w = sorted(set([0, n_w // 2, n_w - 1]))
+            rows = synth_rows(f_w, l_w, dim, planted_w)
+            im.DistDiagonalEnroller(cc, n_w, rank, world).serializeDB(rows, seed=SEED + 7)
+            del rows
+            snd_w = im.DistDiagonalSender(cc, n_w, dist, rank, world, staging="host" if rehearse else "device",
+                                          rotation_split=sender.rotation_split)
+            q_w = im.DiagonalReceiver(cc, n_w).encryptQuery(np.ones(dim), seed=SEED, nonce=1) if rank == 0 else None
+            keep = res
+            timed(snd_w, q_w, 1)
+            dt = timed(snd_w, q_w, 3)
+            ok_w = im.DiagonalReceiver(cc, n_w).decryptIndex(res) == planted_w if rank == 0 else True
+            res = keep
+            weak = {"db_vectors_total": n_w, "db_vectors_per_gpu": 1 << args.log2n, "ms_per_step": round(dt / 3 * 1e3, 3),
+                    "vectors_per_s": round(n_w * 3 / dt), "result_correct": bool(ok_w)}
+            del snd_w, q_w
+        except Exception as e:  # the headline line must not die on the optional figure
+            weak = {"error": repr(e)[:300]}
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         nl, N = cc.nQ, cc.N
@@ -267,15 +368,15 @@ def main():
         achieved = algo_bytes / avg_launch_s / 1e9 if launches else 0.0
         # bytes the kernel has to move given the RESIDENT layout (48-bit residues for the 45/46-bit limbs of the database;
         # rotated queries and accumulators at 8 bytes): what the wire sees when nothing is read twice
-        resident_bytes = cc.db_stats()[2] + dim * 2 * nl * N * 8 + G_local * 3 * nl * N * 8
+        resident_bytes = db_resident_bytes + dim * 2 * nl * N * 8 + G_local * 3 * nl * N * 8
         wire = resident_bytes / avg_launch_s / 1e9 if launches else 0.0
         traffic = traffic_meta = None
         tpath = os.path.join(ROOT, "profiles", "tensor_traffic.json")
         knobs = [k for k in ("HYDIA_DB_UNPACKED", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW") if os.environ.get(k)]
-        if os.path.exists(tpath) and not args.random_db and not knobs and not strong:
+        if os.path.exists(tpath) and not args.random_db and not knobs and world == 1:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("log2n") == args.log2n:
+                if tj.get("log2n") == n_total.bit_length() - 1:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_meta = {"profiled_at_commit": tj.get("commit"), "source": tj.get("source"),
                                     "kernel_source_sha": tj.get("kernel_sha"), "stale": tj.get("kernel_sha") != kernel_sha()}
@@ -283,7 +384,7 @@ def main():
                         traffic = None  # the loop-B kernel changed since the counters were collected: do not quote them
             except Exception:
                 traffic = None
-        db_gib = cc.db_stats()[2] / 2 ** 30
+        db_gib = db_resident_bytes / 2 ** 30
         out = {
             "metric": "encrypted DB vectors matched/sec (HyDia indexScenario, CKKS N=2^15)",
             "value": n_total * args.steps / elapsed,
@@ -293,13 +394,16 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": (n_total * args.steps / elapsed) / PUBLISHED_2P20_INDEX_VPS if (world == 1 and n_total == 1 << 20) else None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB per GPU (%d blocks of 16384; %.0f GiB resident in "
+            "config": {"workload": workload_name(n_total, world, strong) + ": %d blocks of 16384 vectors on this GPU (%.0f GiB resident in "
                                    "HBM as 48-bit residues = %.0f GiB of 8-byte ciphertexts), one query per step through indexScenario"
-                                   % (max(n_local, 1).bit_length() - 1, G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30),
+                                   % (G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30),
                        "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
-                       "sharding": "row-blocks per GPU (image_matching_amd.sharding.DistDiagonalSender): query broadcast, independent "
-                                   "mat-vec per rank, RCCL gather of result ciphertexts in global block order" if multi else "one GPU",
+                       "sharding": "row-blocks per GPU (image_matching_amd.sharding.DistDiagonalSender): query broadcast, loop A %s, "
+                                   "independent mat-vec per rank, RCCL gather of result ciphertexts in global block order"
+                                   % ("shared out over the ranks and all-gathered" if (loop_a and loop_a["mode"] == "split") else "recomputed by every rank")
+                                   if multi else "one GPU",
+                       "loop_a_across_ranks": loop_a,
                        "result_check": "decrypted index of the gathered result == planted matches (global indices)" if not args.random_db else "skipped (random DB)",
                        "result_correct": bool(correct), "setup_s": {"keygen": round(t_keygen, 2), "enroll": round(t_enroll, 2)},
                        "vs_baseline_note": "value / 10 864 vectors/s = the reference's published 2^20 index computation on a 48-thread Xeon "
@@ -319,6 +423,8 @@ def main():
                                  "at the bytes resident in HBM; `traffic` = PMC HBM bytes per launch (profiles/tensor_traffic.json), quoted "
                                  "only while the kernel source it was profiled on is unchanged"},
         }
+        if weak is not None:
+            out["config"]["secondary"] = {"weak_scaling": weak}
         if ms_similarity is not None:
             out["config"]["secondary"] = {"computeSimilarity_ms_per_query": round(ms_similarity, 3),
                                           "computeSimilarity_vectors_per_s": round(n_local / ms_similarity * 1e3),
@@ -335,6 +441,20 @@ def main():
     cc.close()
     if not correct:
         sys.exit(3)
+
+
+def workload_name(n_total, world, strong):
+    """the BASELINE.json configuration a run corresponds to"""
+    lg = n_total.bit_length() - 1
+    if world == 1:
+        tag = {10: "BASELINE config 2 (2^10 DB, one GPU)", 14: "BASELINE config 3 (2^14 DB, one GPU)",
+               20: "BASELINE headline (north_star: 2^20-vector / 512-dim database at 1 GPU)"}.get(lg, "")
+        return "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB on one MI355X%s" % (lg, " = " + tag if tag else "")
+    if strong:
+        tag = " = BASELINE config 5" if (lg, world) == (20, 8) else " = BASELINE config 4" if (lg, world) == (17, 4) else \
+              " (BASELINE config 5's database on %d GPUs)" % world if lg == 20 else ""
+        return "HyDia approach 5, 2^%d-vector x 512-dim encrypted DB sharded by row-blocks across %d x MI355X%s" % (lg, world, tag)
+    return "HyDia approach 5, weak scaling: %d x MI355X with 2^%d vectors each (2^%.2f in all)" % (world, (n_total // world).bit_length() - 1, math.log2(n_total))
 
 
 def kernel_sha():

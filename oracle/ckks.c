@@ -21,6 +21,10 @@
 #define PARFOR _Pragma("omp parallel for schedule(static) if (!omp_in_parallel())")
 
 int hyo_num_threads(void) { return omp_get_max_threads(); }
+/* size of the OpenMP teams of every later parallel region (bench.py: the CPU share this job really has) */
+void hyo_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
 
 /* ------------------------------------------------------------------ encode / decode */
 typedef struct { double re, im; } cplx;

@@ -166,6 +166,7 @@ hy_ct *hyo_hers_membership_scenario(const hy_params *p, const hy_keys *k, hy_ct 
 hy_ct *hyo_ct_at(hy_ct **arr, size_t i);
 void hyo_ct_array_free(hy_ct **arr, size_t n);
 int hyo_num_threads(void);
+void hyo_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,7 @@ def lib():
         "hyo_ct_at": (vp, [vp, C.c_size_t]),
         "hyo_ct_array_free": (None, [vp, C.c_size_t]),
         "hyo_num_threads": (C.c_int, []),
+        "hyo_set_num_threads": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
