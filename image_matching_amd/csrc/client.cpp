@@ -190,6 +190,7 @@ void client_decrypt(Context &cx, const Ct &ct, double *out) {
 }
 
 #define HY_DB_NONCE_BASE (1ull << 36)
+#define HY_NONCE_LIMIT (1ull << 40)
 // DiagonalEnroller::serializeDB: normalise IN PLACE (enroller_diag.cpp:32-35), then per group of `slots` rows: pack the
 // generalised diagonals (:37-45) and encrypt the vector_dim slot vectors (:48-52) into the resident HBM layout.
 void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32], size_t first_block) {
@@ -197,6 +198,9 @@ void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32], si
     for (long long v = 0; v < (long long)n; v++) normalize(db + (size_t)v * dim, dim);
     const ChaChaKey key = make_key(seed);
     const size_t G = cx.db_cts / dim, ct_elems = (size_t)2 * cx.nQ * cx.N;
+    // nonces are a 40-bit field of the sampler stream id: block first_block + g uses HY_DB_NONCE_BASE + (first_block + g) dim ..
+    if (first_block > (HY_NONCE_LIMIT - HY_DB_NONCE_BASE) / (size_t)dim || G > (HY_NONCE_LIMIT - HY_DB_NONCE_BASE) / (size_t)dim - first_block)
+        throw std::runtime_error("hydia: first_block + number of blocks exceeds the 2^40 nonce space of the encryption sampler");
     double *d_rows = (double *)cx.pool.get(sizeof(double) * (size_t)Nh * dim);
     double *d_slots = (double *)cx.pool.get(sizeof(double) * (size_t)dim * Nh);
     u64 *d_cts = cx.pool.get(sizeof(u64) * (size_t)dim * ct_elems);  // one group of fresh ciphertexts before packing

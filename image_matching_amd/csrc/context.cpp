@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <sys/stat.h>
+
 #include "hydia_core.h"
 
 namespace hydia {
@@ -352,6 +354,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
         tabs.two_ip_launches = getenv("HYDIA_RELIN_TWO_IP_LAUNCHES") ? 1 : 0;
         const char *g = getenv("HYDIA_IP_GROUP");
         tabs.ip_group = g && atoi(g) > 0 ? atoi(g) : 8;
+        tabs.generic = getenv("HYDIA_NTT_GENERIC") ? 1 : 0;
     }
     modup_per_digit = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
     loop_a_separate_ip = getenv("HYDIA_LOOPA_SEPARATE_IP") != nullptr;
@@ -363,13 +366,11 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
             if (!((tabs.fp_mask >> m) & 1u) && mod[m].q < (1ull << 60) && (1ull << 60) - mod[m].q < (1ull << 24)) tabs.pm_mask |= 1u << m;
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
-    fuse_bconv = getenv("HYDIA_FUSE_BCONV") != nullptr;
     merge_rescale = getenv("HYDIA_NO_MERGE_RESCALE") == nullptr;
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
     fuse_loop_a = getenv("HYDIA_NO_FUSE_LOOPA") == nullptr;
     colfuse = getenv("HYDIA_NO_COLFUSE") == nullptr;
-    if (const char *e = getenv("HYDIA_SLICE_MIB")) slice_bytes = (size_t)atol(e) << 20;
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)
@@ -578,13 +579,31 @@ void Context::db_load(const char *path) {
     if ((h.packed != 0) != db_packed || h.ct_bytes != db_layout().ct_bytes)
         throw std::runtime_error("hydia: database file layout (48-bit packed / 8-byte) differs from this context's");
     if (h.kind != 4 && h.kind != 5) throw std::runtime_error("hydia: database file has an unknown packing kind");
+    // the header is untrusted input: the ciphertext count must be the one the packing implies for n_vectors (diagonal packing:
+    // ceil(ceil(n / dim) / (slots / dim)) * dim; column packing: ceil(n / slots) * dim), and the file must hold exactly that many
+    // — checked BEFORE anything is allocated or the resident database is touched
+    if (h.n_vectors < 1 || h.n_cts < 1) throw std::runtime_error("hydia: database file header declares an empty database");
+    const uint64_t dim = (uint64_t)prm.dim, S = (uint64_t)slots;
+    const uint64_t G = (h.n_vectors + S - 1) / S;
+    const uint64_t want_cts = h.kind == 5 ? (((h.n_vectors + dim - 1) / dim + S / dim - 1) / (S / dim)) * dim : G * dim;
+    if (h.n_vectors > (UINT64_MAX - S) || h.n_cts != want_cts)
+        throw std::runtime_error("hydia: database file header is inconsistent (ciphertext count does not match the vector count)");
+    {
+        struct stat sb {};
+        if (fstat(fileno(fc.f), &sb) != 0) throw std::runtime_error("hydia: cannot stat the database file");
+        const unsigned __int128 need = (unsigned __int128)h.n_cts * h.ct_bytes + sizeof h;
+        if ((unsigned __int128)sb.st_size < need) throw std::runtime_error("hydia: database file is truncated");
+        if ((unsigned __int128)sb.st_size > need) throw std::runtime_error("hydia: database file has trailing bytes");
+    }
+    sync_all();  // an earlier, still asynchronous query may be reading the resident database this load overwrites
+    db_kind = 0;
     db_resize(h.n_vectors, h.n_cts);
     const size_t total = db_cts * db_layout().ct_bytes;
     PinnedBuf buf(std::min(total, DB_IO_CHUNK));
     for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
         const size_t n = std::min(DB_IO_CHUNK, total - off);
         if (fread(buf.p, 1, n, fc.f) != n) {
-            db_kind = 0;
+            db_vectors = db_cts = 0;  // nothing usable is resident
             throw std::runtime_error("hydia: database file is truncated");
         }
         HIP_CHECK(hipMemcpy(d_db + off, buf.p, n, hipMemcpyHostToDevice));

@@ -213,10 +213,8 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
         return;
     }
     ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
-    const bool fused_conv = prm.logN == 15 && fuse_bconv;
-    if (!fused_conv) hk::base_convert_digits(stream, d_mod, N, y, (size_t)nl * N, dig, dig_x, X, pl.d_tabs, nd, nl, nE, esel);
-    const bool no_merge = modup_per_digit;
-    const bool merged = !fused_conv && !no_merge && nd > 1 && (size_t)X * nd * nE < 128;
+    hk::base_convert_digits(stream, d_mod, N, y, (size_t)nl * N, dig, dig_x, X, pl.d_tabs, nd, nl, nE, esel);
+    const bool merged = !modup_per_digit && nd > 1 && (size_t)X * nd * nE < 128;
     if (merged) {
         if (p1_only) hk::ntt15_forward_p1(stream, tabs, dig, dig, (size_t)nE * N, (size_t)nE * N, X * nd, esel);
         else ntt_fwd(dig, (size_t)nE * N, X * nd, esel);
@@ -227,27 +225,7 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
         LimbSel rest{};
         rest.n = nE - hi;
         for (int t = hi; t < nE; t++) rest.mod[t - hi] = esel.mod[t];
-        if (fused_conv) {
-            // (experiment switch HYDIA_FUSE_BCONV) base conversion fused into the forward NTT's first pass: measured
-            // SLOWER than the separate all-targets kernel (16.8 vs 14.2 ms per 2^20 query: every target limb re-reads
-            // the sources with 8-byte loads and pays its own 128-bit reduction), so it is off by default
-            ConvTab tab{};
-            HIP_CHECK(hipMemcpy(&tab, pl.d_tabs + d, sizeof(ConvTab), hipMemcpyDeviceToHost));
-            NttLoad ld{};
-            ld.mode = 1;
-            ld.y = y + (size_t)lo * N;
-            ld.y_outer = (size_t)nl * N;
-            ld.tab = tab;
-            NttStore stp{};
-            if (lo > 0) {
-                ld.t0 = 0;
-                hk::ntt15_forward_fused(stream, tabs, nullptr, out, 0, dig_x, X, sel_range(0, lo), ld, stp);
-            }
-            if (rest.n > 0) {
-                ld.t0 = hi;
-                hk::ntt15_forward_fused(stream, tabs, nullptr, out + (size_t)hi * N, 0, dig_x, X, rest, ld, stp);
-            }
-        } else if (!merged) {
+        if (!merged) {
             if (p1_only) {  // the caller runs the second pass fused with the inner product
                 if (lo > 0) hk::ntt15_forward_p1(stream, tabs, out, out, dig_x, dig_x, X, sel_range(0, lo));
                 if (rest.n > 0) hk::ntt15_forward_p1(stream, tabs, out + (size_t)hi * N, out + (size_t)hi * N, dig_x, dig_x, X, rest);
@@ -281,9 +259,9 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     // transform's epilogue (NttStore mode 5), so only the special-prime limbs of the accumulator ever exist in HBM — the
     // [X][2][nl][N] part (3 of 4 GiB at X = 511) is neither written nor read back
     const bool premul = keys_packed_nQ > 0 && rotptrs_premul;  // the packed shadow's Q-limb rows already carry P^{-1}
-    if (premul && !(prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !fuse_bconv && !dbl))
+    if (premul && !(prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !dbl))
         throw std::runtime_error("hydia: pre-scaled rotation keys outside the fused loop A");
-    if (prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !fuse_bconv && !dbl) {
+    if (prm.logN == 15 && fuse_loop_a && dig_x_stride == 0 && !same_key && !dbl) {
         if (premul)
             for (int k = 0; k < nP; k++)
                 for (int j = 0; j < nl; j++) tab.f[k][j] = mulmod_u64(Phat_mod_q[k][j], Pinv_mod_q[j], q[j]);
@@ -382,17 +360,9 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
     if (prm.logN == 15) {
         // ModDown combine (+ addend, doubling, automorphism scatter) fused into the NTT's second pass; the P -> Q base
-        // conversion runs as its own all-targets kernel unless HYDIA_FUSE_BCONV asks for the first-pass fusion
+        // conversion runs as its own all-targets kernel
         NttLoad ld{};
-        if (fuse_bconv) {
-            ld.mode = 1;
-            ld.y = y;
-            ld.y_outer = (size_t)nP * N;
-            ld.tab = tab;
-            ld.t0 = 0;
-        } else {
-            hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
-        }
+        hk::base_convert(stream, d_mod, N, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, tab, qsel);
         NttStore stp{};
         stp.mode = 1;
         stp.out = out;
@@ -439,7 +409,7 @@ void Context::build_rotptrs() {
         pack = false;
     }
     // with the fused loop A the shadow's Q-limb rows carry P^{-1} (see k_key_pack): only that path reads them
-    const bool premul = pack && fuse_loop_a && prm.logN == 15 && !fuse_bconv;
+    const bool premul = pack && fuse_loop_a && prm.logN == 15;
     std::vector<u64> pinv_all(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nQ);
     const ScaleSel pinv_sel = scale_of(sel_q(nQ), pinv_all, false);
     for (int i = 1; i < prm.dim; i++) {
@@ -539,36 +509,18 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     }
     if (!relin_key.d) throw StateError("hydia: relinearisation key not loaded");
     if (sub && (sub->X != c.X || sub->npoly != 2 || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
-    // Experiment switch HYDIA_SLICE_MIB (default off): walk the batch in slices whose intermediates (~ (nd + 2)(nl + nP) + 3 nl + 2 l
-    // limb-polynomials per ciphertext) fit the 256 MiB Infinity Cache, so that every producer -> consumer hand-off of a slice finds
-    // its operand in cache.  Measured at 2^20: 66.3 ms unsliced, 76.8 / 110.6 / 206.8 ms at 192 / 96 / 48 MiB — the slices' kernels
-    // last 10-30 us and the query becomes launch-bound (5-20x more launches); kept only so the measurement can be repeated.
-    const int nE0 = nl + nP, nd0 = (nl + alpha - 1) / alpha;
-    const size_t per_ct = ((size_t)(nd0 + 2) * nE0 + 3 * nl + 2 * l) * N * sizeof(u64);
-    const int chunk = slice_bytes ? (int)std::max<size_t>(1, slice_bytes / per_ct) : c.X;
     Ct out(this, c.X, 2, l, c.scale / (double)q[l]);
-    for (int x0 = 0; x0 < c.X; x0 += chunk) {
-        Ct part = c.alias(c.nl);
-        part.X = std::min(chunk, c.X - x0);
-        part.d = c.d + (size_t)x0 * c.ct_elems();
-        Ct sv;
-        if (sub) {
-            sv = sub->alias(sub->nl);
-            sv.X = part.X;
-            sv.d = sub->d + (size_t)x0 * sub->ct_elems();
-        }
-        relin_rescale_slice(part, dbl, sub ? &sv : nullptr, addc, sub_is_add, out.d + (size_t)x0 * out.ct_elems());
-    }
+    relin_rescale_into(c, dbl, sub, addc, sub_is_add, out.d);
     c = std::move(out);
 }
-// one slice of relin_rescale: c [X][3][nl][N] (a view) -> out_d [X][2][nl - 1][N]
-void Context::relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d) {
+// the merged pipeline: c [X][3][nl][N] -> out_d [X][2][nl - 1][N]
+void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d) {
     const int nl = c.nl, l = nl - 1;
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     const u64 *c2 = c.d + 2 * c.poly_elems();
     // the inner product reads a digit's own limbs from c2, and (fuse_ip) consumes the ModUp transforms' second pass directly
-    const bool fip = fuse_ip && !fuse_bconv;
+    const bool fip = fuse_ip;
     modup_digits(c2, c.ct_elems(), X, nl, dig, /*copy_own=*/false, /*p1_only=*/fip);
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
@@ -1234,7 +1186,7 @@ Ct Context::sum_and_evalsum(const Ct &s) {
     return m;
 }
 // Cross-shard membership reduction: partial sums of the shards are added as plain 64-bit integers (what an RCCL
-// all-reduce(SUM) on int64 does: at most 8 residues below 2^60 cannot overflow) and reduced once.
+// all-reduce(SUM) on int64 does: at most 16 residues below 2^60 cannot overflow) and reduced once.
 void Context::add_raw_inplace(Ct &a, const u64 *other) {
     hk::add_raw(stream, d_mod, N, a.d, other, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride, a.nl, a.lstride);
 }

@@ -9,12 +9,13 @@
 //   indexScenario    0.5 MiB per block back to shard 0, placed in GLOBAL block order, so the receiver's
 //                    j + i*batchSize (src/receiver/receiver_hers.cpp:46-49) is already the database index
 //   membership       (sender_diag.cpp:46-47) per shard EvalAddMany over its own blocks; the R partial sums are added as plain
-//                    64-bit integers (at most 16 residues below 2^60) and reduced mod q once, then EvalSum on shard 0 —
+//                    64-bit integers (a group has at most 16 shards: 16 residues below 2^60 fit 64 bits) and reduced mod q once, then EvalSum on shard 0 —
 //                    bit-identical to the unsharded EvalAddMany + EvalSum
 // The multi-process form of the same steps (one rank per GPU, RCCL gather / all-reduce) is image_matching_amd/sharding.py; both
 // are built from the same entry points (hydia_db_enroll_shard, hydia_index_scenario, hydia_add_many, hydia_ct_add_raw,
 // hydia_ct_mod_reduce, hydia_eval_sum).
 #include <algorithm>
+#include <cstdio>
 #include <exception>
 #include <thread>
 
@@ -211,10 +212,18 @@ int hydia_group_create(const hydia_params *p, const int *devices, uint32_t n_sha
             for (uint32_t b = 0; b < n_shards; b++) {
                 const int da = devices[a], db = devices[b];
                 int can = 0;
-                if (da == db || hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) continue;
-                (void)hipSetDevice(da);
-                hipError_t e = hipDeviceEnablePeerAccess(db, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                if (da == db) continue;
+                hipError_t e = hipDeviceCanAccessPeer(&can, da, db);
+                if (e == hipSuccess && can) {
+                    (void)hipSetDevice(da);
+                    e = hipDeviceEnablePeerAccess(db, 0);
+                    if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+                }
+                if (e != hipSuccess || !can) {  // not fatal: hipMemcpyPeerAsync then stages through the host — but say so, once per pair
+                    (void)hipGetLastError();
+                    fprintf(stderr, "hydia: no direct peer access from GPU %d to GPU %d (%s): shard exchanges will be staged through host memory\n",
+                            da, db, e != hipSuccess ? hipGetErrorString(e) : "not supported");
+                }
             }
         *out = g;
         return HYDIA_OK;

@@ -195,7 +195,7 @@ struct Context : HostParams {
     const CfPlan &cf_plan_moddown_rescale(int nl, bool dbl);     // merged ModDown + Rescale from level nl
     const CfPlan &cf_plan_store(const std::string &key, std::vector<ColFuse> &&maps);
     bool colfuse = true;        // HYDIA_NO_COLFUSE: pass 1' / conversion / pass 1 as three kernels
-    bool cf_ok() const { return colfuse && prm.logN == 15 && alpha <= HY_CF_SRC && nP <= HY_CF_SRC && !fuse_bconv; }
+    bool cf_ok() const { return colfuse && prm.logN == 15 && alpha <= HY_CF_SRC && nP <= HY_CF_SRC; }
     LimbSel sel_q(int nl) const;           // limbs 0..nl-1
     LimbSel sel_ext(int nl) const;         // limbs 0..nl-1 then all P limbs
     LimbSel sel_range(int lo, int hi) const;
@@ -224,8 +224,7 @@ struct Context : HostParams {
     // the dropped limb of the ModDown output is obtained in the coefficient domain, so ModDown's and Rescale's
     // corrections share a single forward NTT per remaining limb ((l+1) transforms per polynomial saved)
     void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
-    void relin_rescale_slice(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d);
-    size_t slice_bytes = 0;  // experiment: working set of one slice of a batched key switch (HYDIA_SLICE_MIB; 0 = whole batch)
+    void relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d);
     bool merge_rescale = true;      // HYDIA_NO_MERGE_RESCALE: run the two steps separately (A/B)
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged
@@ -233,7 +232,6 @@ struct Context : HostParams {
     int tensor_nw = 4;              // max waves per workgroup in loop B (HYDIA_TENSOR_NW; 0 = up to 16)
     // round-2 fusions, each with its off switch for the parity variants (read once per context)
     bool modup_per_digit = false, loop_a_separate_ip = false, loop_a_int_ip = false, relin_separate_intt = false;
-    bool fuse_bconv = false;        // HYDIA_FUSE_BCONV: base conversion inside the NTT's first pass (slower, kept for A/B)             // DB blocks served per thread in loop B (HYDIA_TENSOR_BPP)
     void add_inplace(Ct &a, const Ct &b);
     void sub_inplace(Ct &a, const Ct &b);
     void add_const(Ct &a, double c);

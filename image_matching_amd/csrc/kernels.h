@@ -27,6 +27,7 @@ struct NttTables {
     int one_pass_min;              // HYDIA_NTT_1PASS_MIN: smallest launch (limb-polynomials) that takes the one-pass kernel (default 1024)
     int two_ip_launches;           // HYDIA_RELIN_TWO_IP_LAUNCHES: Q and special-prime halves of the fused inner product as two launches
     int ip_group;                  // HYDIA_IP_GROUP: ciphertexts per interleaving group of the merged inner-product kernel (default 8)
+    int generic;                   // HYDIA_NTT_GENERIC: the ring-size-generic transform kernels also at N = 2^15 (parity variant)
 };
 
 // base conversion table: out[t] = sum_s y[s] * f[s][t] mod q_{dst t}
@@ -64,12 +65,10 @@ struct LinCombMulti {
 
 // Fused prologue of the N = 2^15 forward NTT's first pass: where the coefficient-form input comes from
 struct NttLoad {
-    int mode;             // 0 plain (src), 1 fast base conversion from `y`, 2 rescale spread from `y`
-    const u64 *y;         // mode 1: [x][ns][N] source residues (coefficient form); mode 2: [x][N] last limb, coefficient form
+    int mode;             // 0 plain (src), 2 rescale spread from `y`
+    const u64 *y;         // mode 2: [x][N] last limb, coefficient form
     size_t y_outer;       // elements between consecutive x
     int l;                // mode 2: index of the dropped modulus q_l
-    ConvTab tab;          // mode 1: f[s][t] for target slot t (skip range ignored: launch only the wanted slots)
-    int t0;               // mode 1: target slot of sel slot 0 (tab column = t0 + slot)
 };
 // Fused epilogue of its second pass: what is done with the evaluation-form value v of limb j
 // store mode 4: the forward transform's results are consumed by the key-switching inner product instead of being stored —

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_addsub(const ModC *__restrict__ mod, in
     r.y = OP == 0 ? addmod(va.y, vb.y, q) : OP == 1 ? submod(va.y, vb.y, q) : va.y + vb.y;
     *reinterpret_cast<ulonglong2 *>(o + (size_t)xp * o_ls * N + i) = r;
 }
-// any 64-bit value -> canonical residue of its limb (after an integer all-reduce of at most 8 residues < 2^60)
+// any 64-bit value -> canonical residue of its limb (after an integer all-reduce of at most 16 residues < 2^60)
 __global__ __launch_bounds__(256) void k_mod_reduce(const ModC *__restrict__ mod, int N, u64 *a, LimbSel sel, int a_ls) {
     const int y = blockIdx.y, xp = y / sel.n, slot = y - xp * sel.n;
     const ModC M = mod[sel.mod[slot]];
@@ -747,13 +747,9 @@ size_t ledger_dump(char *out, size_t cap) {
 }
 #define LP_BYTES(N) ((double)(N) * 8.0)
 
-static bool use_generic_ntt() {
-    static const bool g = getenv("HYDIA_NTT_GENERIC") != nullptr;
-    return g;
-}
 void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                  const LimbSel &sel) {
-    if (logN == 15 && !use_generic_ntt()) return ntt15_forward(st, T, src, dst, so, dso, X, sel);
+    if (logN == 15 && !T.generic) return ntt15_forward(st, T, src, dst, so, dso, X, sel);
     const int N = 1 << logN, R = N >> 8;
     ScaleSel dummy = {};
     hipLaunchKernelGGL(k_ntt_strided<false>, dim3(8, X * sel.n), dim3(256), (size_t)R * 32 * 8, st, T, logN, src, dst, so,
@@ -762,7 +758,7 @@ void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u
 }
 void ntt_inverse(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                  const LimbSel &sel, const ScaleSel &scale) {
-    if (logN == 15 && !use_generic_ntt()) return ntt15_inverse(st, T, src, dst, so, dso, X, sel, scale);
+    if (logN == 15 && !T.generic) return ntt15_inverse(st, T, src, dst, so, dso, X, sel, scale);
     const int N = 1 << logN, R = N >> 8;
     hipLaunchKernelGGL(k_ntt_contig<true>, dim3(N / 2048, X * sel.n), dim3(256), 0, st, T, logN, src, dst, so, dso, sel);
     hipLaunchKernelGGL(k_ntt_strided<true>, dim3(8, X * sel.n), dim3(256), (size_t)R * 32 * 8, st, T, logN, dst, dst, dso,
@@ -825,9 +821,8 @@ void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, 
 // conversion kernels let one thread produce every target limb (sources read once).  With few polynomials that is N/512 * X
 // workgroups, each a long serial chain: below ~2 workgroups per CU the targets are sliced over grid.z instead (sources come from L2)
 static int small_launch_targets(int N, int X, int nt) {
-    static const bool off = getenv("HYDIA_NO_TARGET_SLICES") != nullptr;
     const int wgs = (N / 512) * X;
-    if (off || nt <= 1 || wgs >= 512) return nt > 0 ? nt : 1;
+    if (nt <= 1 || wgs >= 512) return nt > 0 ? nt : 1;
     const int slices = std::min(nt, (512 + wgs - 1) / wgs);
     return (nt + slices - 1) / slices;
 }
@@ -901,8 +896,7 @@ template <int BPP, int NW>
 static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G, int dim,
                           int nl, const DbLayout &L) {
     const int Gq = G / (BPP * NW);
-    static const int xcd_map = getenv("HYDIA_TENSOR_NOXCD") ? 0 : 1;
-    const int xm = (N / 128) % 8 == 0 ? xcd_map : 0;
+    const int xm = (N / 128) % 8 == 0 ? 1 : 0;  // XCD-aware tile -> workgroup map
     const unsigned char *dbb = (const unsigned char *)db;
     const dim3 blk(64 * NW);
     {   // resident database (6- or 8-byte residues) + rotated queries once + accumulators, split limb 0 / other limbs like the launches

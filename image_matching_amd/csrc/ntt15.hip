@@ -31,14 +31,6 @@ namespace {
 template <int LD>
 DEV u64 p1_load(const NttLoad &ld, const ModC *__restrict__ mod, const ModC &M, const u64 *s, int x, int slot, size_t idx) {
     if (LD == 0) return s[idx];
-    if (LD == 1) {  // fast base conversion: sum_s y_s[idx] * f[s][t], 128-bit lazy accumulation (ns <= 8, terms < 2^120)
-        const u64 *y = ld.y + (size_t)x * ld.y_outer + idx;
-        u128 acc = 0;
-#pragma unroll
-        for (int k = 0; k < HY_MAX_DIGIT; k++)
-            if (k < ld.tab.ns) acc += (u128)y[(size_t)k * 32768] * ld.tab.f[k][ld.t0 + slot];
-        return reduce128(acc, M);
-    }
     // LD == 2: rescale spread: centred residue of the dropped limb's coefficient
     const u64 ql = mod[ld.l].q, v = ld.y[(size_t)x * ld.y_outer + idx];
     return v > (ql >> 1) ? negmod(reduce64(ql - v, M), M.q) : reduce64(v, M);
@@ -1134,7 +1126,7 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
 // limb-polynomials (default 1024); HYDIA_NTT_1PASS=plain restricts it to transforms without fused prologue / epilogue.
 static bool use_one_pass(const NttTables &T, bool inv, int ld, int st, int items) {
     (void)inv;
-    if (!T.one_pass || ld == 1) return false;
+    if (!T.one_pass) return false;
     if (T.one_pass == 2 && !(ld == 0 && st == 0)) return false;  // "plain": only transforms without a fused prologue / epilogue
     return items >= T.one_pass_min;
 }
@@ -1176,17 +1168,13 @@ template <int LD>
 static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                           const LimbSel &sel, int slot0, int nsl, const NttLoad &ld) {
     ScaleSel dummy = {};
-    ledger_add(LD == 0 ? "k_ntt15_p1<false, 0>" : LD == 1 ? "k_ntt15_p1<false, 1>" : "k_ntt15_p1<false, 2>",
+    ledger_add(LD == 0 ? "k_ntt15_p1<false, 0>" : "k_ntt15_p1<false, 2>",
                (LD == 2 ? 1.0 + 1.0 / (nsl > 0 ? nsl : 1) : 2.0) * X * nsl * 262144.0);  // LD 2 reads ONE dropped limb per polynomial
     hipLaunchKernelGGL((k_ntt15_p1<false, LD>), dim3(8, X * nsl), dim3(256), 0, st, T, src, dst, so, dso, sel, slot0, nsl, dummy, ld);
 }
-// two polynomials per workgroup share the twiddle loads; HYDIA_NTT_NP1: always one.  Small launches (below 4 workgroups per CU
-// when paired — the per-query fixed-cost tail) run one polynomial per workgroup: twice the workgroups, half the serial work in each
-static bool pair_polys(int X, int nsl) {
-    static const bool v = getenv("HYDIA_NTT_NP1") == nullptr;
-    static const bool small_np1 = getenv("HYDIA_NTT_SMALL_PAIRS") == nullptr;
-    return v && X % 2 == 0 && (!small_np1 || (X / 2) * nsl * 16 >= 1024);
-}
+// two polynomials per workgroup share the twiddle loads.  Small launches (below 4 workgroups per CU when paired — the per-query
+// fixed-cost tail) run one polynomial per workgroup: twice the workgroups, half the serial work in each
+static bool pair_polys(int X, int nsl) { return X % 2 == 0 && (X / 2) * nsl * 16 >= 1024; }
 template <int ST>
 static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl,
                           const NttStore &stp) {
@@ -1244,14 +1232,6 @@ void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t
 }
 void ntt15_forward_fused(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X,
                          const LimbSel &sel, const NttLoad &ld, const NttStore &stp) {
-    if (ld.mode == 1) {  // base conversion inside pass 1 (HYDIA_FUSE_BCONV experiment): two-pass kernels only
-        launch_p1_fwd<1>(st, T, src, dst, so, dso, X, sel, 0, sel.n, ld);
-        if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, 0, sel.n, stp);
-        else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, 0, sel.n, stp);
-        else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, 0, sel.n, stp);
-        else launch_p2_fwd<0>(st, T, dst, dso, X, sel, 0, sel.n, stp);
-        return;
-    }
     if (ld.mode == 2) {
         if (stp.mode == 2) forward_runs<2, 2>(st, T, src, dst, so, dso, X, sel, ld, stp);
         else forward_runs<2, 0>(st, T, src, dst, so, dso, X, sel, ld, stp);

@@ -1,10 +1,14 @@
 // include/hydia_roles.hpp — the reference's C++ role surface for approach 5 (HyDia) and approach 4 (HERS), over the C-ABI of hydia.h.
 //
 // Same class and method names as /root/reference/include/{sender,sender_diag,receiver,receiver_hers,receiver_diag,
-// enroller_diag}.h so that src/main.cpp's case 5 (:245-247, :324-327, :333-374) reads unchanged; the OpenFHE handle
-// types are replaced by thin handles onto HBM-resident objects:
-//     CryptoContext<DCRTPoly> + PublicKey + PrivateKey  ->  hydia::CryptoContext (context + keys + resident database)
-//     Ciphertext<DCRTPoly>                               ->  hydia::Ciphertext   (one element of a device batch)
+// enroller_diag,enroller_hers}.h and the same constructor arguments (include/sender.h:22 `(cc, pk, numVectors)`,
+// include/receiver.h:20-21 `(cc, pk, sk, numVectors)`, include/enroller_hers.h:19), so that src/main.cpp's cases 4 and 5
+// (:183-192, :243-247, :319-327, :333-374) read unchanged; the OpenFHE handle types are replaced by thin handles onto HBM-resident
+// objects:
+//     CryptoContext<DCRTPoly>            ->  hydia::CryptoContext (context + keys + resident database)
+//     PublicKey / PrivateKey<DCRTPoly>   ->  hydia::PublicKey / PrivateKey (placeholders: the key material lives in the context)
+//     Ciphertext<DCRTPoly>               ->  hydia::Ciphertext   (one element of a device batch)
+// `using namespace hydia::ofhe;` gives these the reference's template spelling (Ciphertext<DCRTPoly>, ...).
 // Randomness: like the reference (OpenFHE seeds its PRNG from the OS) every role object draws its 32-byte sampler key from the
 // operating system (hydia_random_seed) unless the caller passes one for reproducibility; nonces count up per object.
 // Error behaviour mirrors the reference: a message on cerr and carry on (src/sender/sender_diag.cpp:89-91); the
@@ -34,6 +38,24 @@ inline void role_seed(uint8_t out[32], const uint8_t *seed32) {
         std::abort();  // never encrypt under a predictable key
     }
 }
+
+class CryptoContextImpl;
+// Placeholders for OpenFHE's PublicKey<DCRTPoly> / PrivateKey<DCRTPoly>: the key material stays inside the context (HBM), the
+// handles only say "this context's keys" so that the reference's constructor calls keep their shape.
+struct PublicKey {
+    const CryptoContextImpl *owner = nullptr;
+    explicit operator bool() const { return owner != nullptr; }
+};
+struct PrivateKey {
+    const CryptoContextImpl *owner = nullptr;
+    explicit operator bool() const { return owner != nullptr; }
+};
+struct KeyPair {  // what cc->KeyGen() returns (src/main.cpp:183-185)
+    PublicKey publicKey;
+    PrivateKey secretKey;
+    bool good() const { return (bool)publicKey && (bool)secretKey; }
+    explicit operator bool() const { return good(); }
+};
 
 class CryptoContextImpl {
   public:
@@ -76,13 +98,20 @@ class CryptoContextImpl {
     }
     size_t GetRingDimension() const { return info.n; }
     size_t GetBatchSize() const { return info.slots; }
-    // cc->KeyGen(); EvalMultKeyGen; EvalSumKeyGen; EvalRotateKeyGen (src/main.cpp:184-206) in one call; seed32 == nullptr
-    // draws the key material from the OS
-    bool KeyGen(const uint8_t *seed32 = nullptr) {
+    // cc->KeyGen() (src/main.cpp:183): secret, public, relinearisation, rotation {1..dim-1, dim*2^k} keys in ONE call — everything
+    // EvalMultKeyGen / EvalSumKeyGen / EvalRotateKeyGen (:187-206) would add; seed32 == nullptr draws the key material from the OS.
+    // The returned pair is empty (good() == false) when generation failed.
+    KeyPair KeyGen(const uint8_t *seed32 = nullptr) {
         uint8_t seed[32];
         role_seed(seed, seed32);
-        return check(group ? hydia_group_keygen(group, seed) : hydia_keygen(h, seed), "key generation");
+        if (!check(group ? hydia_group_keygen(group, seed) : hydia_keygen(h, seed), "key generation")) return KeyPair{};
+        return KeyPair{PublicKey{this}, PrivateKey{this}};
     }
+    // src/main.cpp:187-206: the evaluation keys exist since KeyGen; these keep the reference's call sequence compiling
+    void EvalMultKeyGen(const PrivateKey &) {}
+    void EvalSumKeyGen(const PrivateKey &) {}
+    template <class IndexList>
+    void EvalRotateKeyGen(const PrivateKey &, const IndexList &) {}
 };
 using CryptoContext = std::shared_ptr<CryptoContextImpl>;
 
@@ -134,6 +163,19 @@ inline std::vector<Ciphertext> split_batch(const CryptoContext &cc, hydia_ct *h)
     return v;
 }
 
+// the reference's template spelling of the handle types: `using namespace hydia::ofhe;` in place of `using namespace lbcrypto;`
+namespace ofhe {
+struct DCRTPoly {};
+template <class Element>
+using CryptoContext = ::hydia::CryptoContext;
+template <class Element>
+using Ciphertext = ::hydia::Ciphertext;
+template <class Element>
+using PublicKey = ::hydia::PublicKey;
+template <class Element>
+using PrivateKey = ::hydia::PrivateKey;
+}  // namespace ofhe
+
 namespace OpenFHEWrapper {
 // src/openFHE_wrapper.cpp:6-44
 inline size_t computeRequiredDepth(size_t approach) { return hydia_compute_required_depth(approach); }
@@ -150,6 +192,7 @@ inline std::vector<double> decryptToVector(CryptoContext cc, Ciphertext ctxt) {
 class Sender {
   public:
     Sender(CryptoContext ccParam, size_t vectorParam) : cc(std::move(ccParam)), numVectors(vectorParam) {}
+    Sender(CryptoContext ccParam, PublicKey pkParam, size_t vectorParam) : cc(std::move(ccParam)), pk(pkParam), numVectors(vectorParam) {}  // include/sender.h:22
     virtual ~Sender() = default;
     virtual std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) = 0;
     virtual Ciphertext membershipScenario(std::vector<Ciphertext> &queryCipher) = 0;
@@ -157,6 +200,7 @@ class Sender {
 
   protected:
     CryptoContext cc;
+    PublicKey pk;
     size_t numVectors;
 };
 // ---- include/sender_diag.h:5-28 (HersSender, approach 4, is further down).  On a sharded context (GenShardedCryptoContext)
@@ -165,6 +209,7 @@ class Sender {
 class DiagonalSender : public Sender {
   public:
     DiagonalSender(CryptoContext ccParam, size_t vectorParam) : Sender(std::move(ccParam), vectorParam) {}
+    DiagonalSender(CryptoContext ccParam, PublicKey pkParam, size_t vectorParam) : Sender(std::move(ccParam), pkParam, vectorParam) {}
     std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) override {
         hydia_ct *out = run(queryCipher, hydia_compute_similarity, hydia_group_compute_similarity, "computeSimilarity");
         return out ? split_batch(cc, out) : std::vector<Ciphertext>{};
@@ -194,7 +239,13 @@ class DiagonalSender : public Sender {
 // ---- include/receiver.h:17-43, include/receiver_hers.h, include/receiver_diag.h
 class Receiver {
   public:
-    Receiver(CryptoContext ccParam, size_t vectorParam) : cc(std::move(ccParam)), numVectors(vectorParam) {}
+    Receiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr) : cc(std::move(ccParam)), numVectors(vectorParam) {
+        role_seed(seed, seed32);
+    }
+    Receiver(CryptoContext ccParam, PublicKey pkParam, PrivateKey skParam, size_t vectorParam)  // include/receiver.h:20-21
+        : cc(std::move(ccParam)), pk(pkParam), sk(skParam), numVectors(vectorParam) {
+        role_seed(seed, nullptr);
+    }
     virtual ~Receiver() = default;
     virtual std::vector<Ciphertext> encryptQuery(std::vector<double> query) = 0;
     virtual bool decryptMembership(Ciphertext &membershipCipher) = 0;
@@ -202,11 +253,24 @@ class Receiver {
 
   protected:
     CryptoContext cc;
+    PublicKey pk;
+    PrivateKey sk;
     size_t numVectors;
+    uint8_t seed[32];    // this object's sampler key (OS entropy unless supplied); nonces count up per object
+    uint64_t nonce = 0;
 };
+// approach 4's receiver (include/receiver_hers.h:9-28); DiagonalReceiver inherits its decrypt* and overrides encryptQuery
 class HersReceiver : public Receiver {
   public:
     using Receiver::Receiver;
+    // src/receiver/receiver_hers.cpp:13-24: vector_dim ciphertexts, one per dimension
+    std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
+        hydia_ct *out = nullptr;
+        if (query.size() < cc->info.vector_dim) query.resize(cc->info.vector_dim, 0.0);
+        nonce += cc->info.vector_dim;
+        if (!cc->check(hydia_hers_encrypt_query(cc->h, query.data(), seed, nonce, &out), "encryptQuery")) return {};
+        return split_batch(cc, out);
+    }
     // src/receiver/receiver_hers.cpp:26-35
     bool decryptMembership(Ciphertext &membershipCipher) override {
         if (!membershipCipher) return false;
@@ -225,12 +289,10 @@ class HersReceiver : public Receiver {
         return outputValues;
     }
 };
+using HersQueryReceiver = HersReceiver;  // round-2 name of the approach-4 receiver
 class DiagonalReceiver : public HersReceiver {
   public:
-    DiagonalReceiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
-        : HersReceiver(std::move(ccParam), vectorParam) {
-        role_seed(seed, seed32);
-    }
+    using HersReceiver::HersReceiver;
     // src/receiver/receiver_diag.cpp:13-26
     std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
         hydia_ct *out = nullptr;
@@ -238,38 +300,64 @@ class DiagonalReceiver : public HersReceiver {
         if (!cc->check(hydia_encrypt_query(cc->h, query.data(), seed, ++nonce, &out), "encryptQuery")) return {};
         return split_batch(cc, out);
     }
-
-  private:
-    uint8_t seed[32];
-    uint64_t nonce = 0;
 };
 
-// ---- include/enroller_diag.h:7-27
-class DiagonalEnroller {
-  public:
-    DiagonalEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
-        : cc(std::move(ccParam)), numVectors(vectorParam) {
-        role_seed(seed, seed32);
+// ---- enrollers.  Randomness: without a caller-supplied seed EVERY serializeDB call draws a fresh sampler key from the OS (the
+// database nonces restart at the same base on every call, so a key must never serve two enrolments: ct2 - ct1 would be the
+// plaintext difference); with a supplied seed (reproducible tests) a second enrolment on the same object is refused.
+class EnrollerBase {
+  protected:
+    EnrollerBase(CryptoContext ccParam, PublicKey pkParam, size_t vectorParam, const uint8_t *seed32)
+        : cc(std::move(ccParam)), pk(pkParam), numVectors(vectorParam), own_seed(seed32 == nullptr) {
+        if (seed32) role_seed(seed, seed32);
     }
-    // src/enroller/enroller_diag.cpp:12-53 — normalises `database` in place; ciphertexts go to HBM, not to
-    // serial/db_diagonal/index<t>.bin
-    void serializeDB(std::vector<std::vector<double>> &database) {
+    bool next_seed(const char *what) {
+        if (own_seed) {
+            role_seed(seed, nullptr);
+        } else if (enrolled) {
+            cc->last_status = HYDIA_ERR_STATE;
+            std::cerr << "Error: " << what << ": a caller-supplied seed enrols ONE database; construct a new enroller" << std::endl;
+            return false;
+        }
+        enrolled = true;
+        return true;
+    }
+    std::vector<double> flatten(const std::vector<std::vector<double>> &database) const {
         const size_t dim = cc->info.vector_dim;
         std::vector<double> flat(numVectors * dim, 0.0);
         for (size_t i = 0; i < numVectors && i < database.size(); i++)
             for (size_t j = 0; j < dim && j < database[i].size(); j++) flat[i * dim + j] = database[i][j];
+        return flat;
+    }
+    void write_back(const std::vector<double> &flat, std::vector<std::vector<double>> &database) const {  // normalised in place
+        const size_t dim = cc->info.vector_dim;
+        for (size_t i = 0; i < numVectors && i < database.size(); i++)
+            for (size_t j = 0; j < dim && j < database[i].size(); j++) database[i][j] = flat[i * dim + j];
+    }
+    CryptoContext cc;
+    PublicKey pk;
+    size_t numVectors;
+    uint8_t seed[32] = {};
+    bool own_seed, enrolled = false;
+};
+// ---- include/enroller_diag.h:7-27
+class DiagonalEnroller : public EnrollerBase {
+  public:
+    DiagonalEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
+        : EnrollerBase(std::move(ccParam), PublicKey{}, vectorParam, seed32) {}
+    DiagonalEnroller(CryptoContext ccParam, PublicKey pkParam, size_t vectorParam)  // src/main.cpp:246
+        : EnrollerBase(std::move(ccParam), pkParam, vectorParam, nullptr) {}
+    // src/enroller/enroller_diag.cpp:12-53 — normalises `database` in place; ciphertexts go to HBM, not to
+    // serial/db_diagonal/index<t>.bin
+    void serializeDB(std::vector<std::vector<double>> &database) {
+        if (!next_seed("serializeDB")) return;
+        std::vector<double> flat = flatten(database);
         if (!cc->check(cc->group ? hydia_group_db_enroll(cc->group, flat.data(), numVectors, seed)
                                  : hydia_db_enroll(cc->h, flat.data(), numVectors, seed),
                        "serializeDB"))
             return;
-        for (size_t i = 0; i < numVectors && i < database.size(); i++)
-            for (size_t j = 0; j < dim && j < database[i].size(); j++) database[i][j] = flat[i * dim + j];
+        write_back(flat, database);
     }
-
-  protected:
-    CryptoContext cc;
-    size_t numVectors;
-    uint8_t seed[32];
 };
 
 // ---- HERS, approach 4: include/sender_hers.h:9-44, include/receiver_hers.h:9-28, include/enroller_hers.h:16-37.
@@ -277,6 +365,7 @@ class DiagonalEnroller {
 class HersSender : public Sender {
   public:
     HersSender(CryptoContext ccParam, size_t vectorParam) : Sender(std::move(ccParam), vectorParam) {}
+    HersSender(CryptoContext ccParam, PublicKey pkParam, size_t vectorParam) : Sender(std::move(ccParam), pkParam, vectorParam) {}
     std::vector<Ciphertext> computeSimilarity(std::vector<Ciphertext> &queryCipher) override {
         hydia_ct *out = nullptr;
         if (queryCipher.empty() || !queryCipher[0] ||
@@ -299,44 +388,18 @@ class HersSender : public Sender {
         return split_batch(cc, out);
     }
 };
-class HersQueryReceiver : public HersReceiver {  // HersReceiver with its own encryptQuery (receiver_hers.cpp:13-24)
-  public:
-    HersQueryReceiver(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
-        : HersReceiver(std::move(ccParam), vectorParam) {
-        role_seed(seed, seed32);
-    }
-    std::vector<Ciphertext> encryptQuery(std::vector<double> query) override {
-        hydia_ct *out = nullptr;
-        if (query.size() < cc->info.vector_dim) query.resize(cc->info.vector_dim, 0.0);
-        nonce += cc->info.vector_dim;
-        if (!cc->check(hydia_hers_encrypt_query(cc->h, query.data(), seed, nonce, &out), "encryptQuery")) return {};
-        return split_batch(cc, out);
-    }
-
-  private:
-    uint8_t seed[32];
-    uint64_t nonce = 0;
-};
-class HersEnroller {
+class HersEnroller : public EnrollerBase {  // include/enroller_hers.h:16-37
   public:
     HersEnroller(CryptoContext ccParam, size_t vectorParam, const uint8_t *seed32 = nullptr)
-        : cc(std::move(ccParam)), numVectors(vectorParam) {
-        role_seed(seed, seed32);
-    }
+        : EnrollerBase(std::move(ccParam), PublicKey{}, vectorParam, seed32) {}
+    HersEnroller(CryptoContext ccParam, PublicKey pkParam, size_t vectorParam)  // src/main.cpp:243
+        : EnrollerBase(std::move(ccParam), pkParam, vectorParam, nullptr) {}
     void serializeDB(std::vector<std::vector<double>> &database) {  // enroller_hers.cpp:40-93
-        const size_t dim = cc->info.vector_dim;
-        std::vector<double> flat(numVectors * dim, 0.0);
-        for (size_t i = 0; i < numVectors && i < database.size(); i++)
-            for (size_t j = 0; j < dim && j < database[i].size(); j++) flat[i * dim + j] = database[i][j];
+        if (!next_seed("serializeDB")) return;
+        std::vector<double> flat = flatten(database);
         if (!cc->check(hydia_hers_db_enroll(cc->h, flat.data(), numVectors, seed), "serializeDB")) return;
-        for (size_t i = 0; i < numVectors && i < database.size(); i++)
-            for (size_t j = 0; j < dim && j < database[i].size(); j++) database[i][j] = flat[i * dim + j];
+        write_back(flat, database);
     }
-
-  protected:
-    CryptoContext cc;
-    size_t numVectors;
-    uint8_t seed[32];
 };
 
 }  // namespace hydia

@@ -300,3 +300,68 @@ def test_custom_chain_full_ring_end_to_end(im):
     assert receiver.decryptMembership(sender.membershipScenario(qc)) is True
     assert receiver.decryptIndex(sender.indexScenario(qc)) == [0]
     cc.close()
+
+
+ENROLLER_SEED_PROGRAM = r"""
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "hydia_roles.hpp"
+// exit code 0 = every check holds.  (a) an enroller WITHOUT a caller seed enrols the same plaintext database twice: the resident
+// ciphertexts differ (a fresh sampler key per serializeDB call) and both answer the query; (b) an enroller WITH a caller seed refuses
+// a second enrolment (HYDIA_ERR_STATE) and leaves the first database resident.
+int main() {
+    using namespace hydia;
+    CryptoContext cc = GenCryptoContext(11, 45, 64, 11);
+    if (!cc->h || !cc->KeyGen()) return 10;
+    const size_t n = 300, dim = 64;
+    std::vector<std::vector<double>> db(n, std::vector<double>(dim, 1.0));
+    for (size_t i = 1; i < n; i++)
+        for (size_t j = 0; j < dim; j++) db[i][j] = (double)((int)((i * 31 + j * 17) % 199) - 99);
+    const size_t words = 2ull * cc->info.n_q * cc->info.n;
+    std::vector<uint64_t> a(words), b(words);
+    DiagonalEnroller free_seed(cc, PublicKey{cc.get()}, n);
+    std::vector<std::vector<double>> d1 = db, d2 = db;
+    free_seed.serializeDB(d1);
+    if (hydia_db_export_ct(cc->h, 0, a.data()) != 0) return 11;
+    free_seed.serializeDB(d2);
+    if (hydia_db_export_ct(cc->h, 0, b.data()) != 0) return 12;
+    if (std::memcmp(a.data(), b.data(), words * 8) == 0) return 13;          // same (seed, nonce) reused
+    size_t same = 0;
+    for (size_t i = 0; i < words; i++) same += a[i] == b[i];
+    if (same > words / 1000) return 14;                                       // both components re-randomised
+    DiagonalReceiver receiver(cc, PublicKey{cc.get()}, PrivateKey{cc.get()}, n);
+    DiagonalSender sender(cc, PublicKey{cc.get()}, n);
+    auto q = receiver.encryptQuery(std::vector<double>(dim, 1.0));
+    auto idx = sender.indexScenario(q);
+    auto found = receiver.decryptIndex(idx);
+    if (found.empty() || found[0] != 0) return 15;
+    uint8_t seed[32] = {7};
+    DiagonalEnroller fixed(cc, n, seed);
+    std::vector<std::vector<double>> d3 = db;
+    fixed.serializeDB(d3);
+    if (cc->last_status != 0) return 16;
+    if (hydia_db_export_ct(cc->h, 0, a.data()) != 0) return 17;
+    fixed.serializeDB(d3);                                                     // refused, message on cerr
+    if (cc->last_status != HYDIA_ERR_STATE) return 18;
+    if (hydia_db_export_ct(cc->h, 0, b.data()) != 0 || std::memcmp(a.data(), b.data(), words * 8) != 0) return 19;
+    return 0;
+}
+"""
+
+
+def test_role_enroller_never_reuses_a_sampler_key(tmp_path):
+    """Round-2 advisor finding: the C++ DiagonalEnroller drew its sampler key once per object while the database nonces restart at
+    the same base on every serializeDB — two enrolments on one object encrypted under the same (seed, nonce) pairs.  Now every call
+    without a caller seed redraws the key, and a caller-supplied seed enrols one database only."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, exe = tmp_path / "enroller_seed.cpp", tmp_path / "enroller_seed"
+    src.write_text(ENROLLER_SEED_PROGRAM)
+    libdir = os.path.join(root, "image_matching_amd")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"), "-o", str(exe), str(src), "-L", libdir, "-lhydia",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+    assert "ONE database" in out.stderr

@@ -114,6 +114,34 @@ def test_three_block_sender_bit_exact_full_ring(im, full):
     assert receiver.decryptMembership(gmem) is True
 
 
+def test_config3_one_full_block_bit_exact_full_ring(im, full):
+    """BASELINE config 3 in its stated form: n = 16384 exactly (one FULL block, all 32 sub-blocks of every ciphertext populated):
+    similarity, index and membership ciphertexts equal the oracle's; answers = the planted matches, incl. the last slot."""
+    P, K, Or, cc = full
+    n = 16384
+    rng = np.random.default_rng(14)
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
+    planted = [0, 8191, n - 1]
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    query = np.ones(512)
+    cos = (db / np.linalg.norm(db, axis=1, keepdims=True)) @ (query / np.linalg.norm(query))
+    dbc = Or.enroll(db.copy(), 8)
+    im.DiagonalEnroller(cc, n).serializeDB(db, seed=8)
+    assert cc.db_stats()[:2] == (n, 512) and len(dbc) == 512
+    q = Or.encrypt_query(query, 2, 9)
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    gq = receiver.encryptQuery(query, seed=2, nonce=9)
+    sim, gsim = Or.compute_similarity(q, dbc, n), sender.computeSimilarity(gq)
+    assert len(sim) == 1 and np.array_equal(gsim.export()[0], sim[0].data())
+    assert np.abs(cc.decrypt(gsim)[0] - cos).max() < TOL
+    idx, gidx = Or.index_scenario(q, dbc, n), sender.indexScenario(gq)
+    assert np.array_equal(gidx.export()[0], idx[0].data())
+    assert receiver.decryptIndex(gidx) == planted == Or.decrypt_index(idx)
+    mem, gmem = Or.membership_scenario(q, dbc, n), sender.membershipScenario(gq)
+    assert np.array_equal(gmem.export()[0], mem.data()) and receiver.decryptMembership(gmem) is True
+
+
 def test_gpu_comparator_reproduces_published_transfer_curve(im, full):
     """(iii) chebyshevCompare(0.44, 10) on the GPU, decrypted, against the reference's own published output."""
     P, K, Or, cc = full

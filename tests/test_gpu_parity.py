@@ -151,6 +151,30 @@ def test_comparator_depths_and_guard(small):
     assert np.array_equal(same.export()[0], ct.data())
 
 
+def test_comparator_depths_11_to_15(im):
+    """The upper half of the reference's DEPTH_TO_DEGREE table (src/openFHE_wrapper.cpp:153-155: degrees 119 .. 2031) on a 16-level
+    chain at the reduced ring: GPU == oracle bit for bit at every depth, and the decrypted output within 1e-4 of the plain composite
+    (approach 5 itself runs depth 10; these are the rest of chebyshevCompare's contract)."""
+    from test_oracle_path import numpy_compare_plain
+    P = O.Params(log_n=11, depth=16, dim=64)
+    K = O.Keys(P, 5, rotations=[])
+    Or = O.Oracle(P, K)
+    cc = make_ctx(im, P)
+    load_keys(cc, K, [])
+    x = np.linspace(-1, 1, P.slots)
+    ct = Or.encrypt(x, 3, 1)
+    P.L.hyo_drop_to(P.h, ct.h, P.nQ - 1)
+    g = cc.import_ct(ct.data(), ct.scale)
+    for depth, degree in ((11, 119), (12, 247), (13, 495), (14, 1007), (15, 2031)):
+        want = Or.chebyshev_compare(ct, 0.44, depth)
+        got = cc.chebyshev_compare(g, 0.44, depth)
+        assert got.shape()[:3] == (1, 2, P.nQ - 1 - depth)
+        assert np.array_equal(got.export()[0], want.data()), depth
+        assert np.abs(Or.decrypt(want) - numpy_compare_plain(x, 0.44, degree)).max() < TOL, depth
+    assert np.array_equal(cc.chebyshev_compare(g, 0.44, 16).export()[0], ct.data())  # :146-149: outside 7..15 -> unchanged
+    cc.close()
+
+
 def test_error_behaviour(im, small):
     P, K, Or, cc = small
     fresh = make_ctx(im, P)
@@ -292,6 +316,10 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         {"HYDIA_NTT_NO_PM": "1", "HYDIA_RELIN_TWO_IP_LAUNCHES": "1"},
         # round 3: pass 1' / base conversion / pass 1 as three kernels instead of the column-fused one (default arithmetics)
         {"HYDIA_NO_COLFUSE": "1"},
+        # the remaining launch-shape switches: loop B one block per wave / two waves per workgroup, interleaving group 1 in the merged
+        # inner product; the ring-size-generic transform kernels wherever a plain transform runs (unfused pipeline)
+        {"HYDIA_TENSOR_BPP": "1", "HYDIA_TENSOR_NW": "2", "HYDIA_IP_GROUP": "1"},
+        {"HYDIA_NTT_GENERIC": "1", "HYDIA_NO_COLFUSE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_NO_MERGE_RESCALE": "1"},
         # the unfused pipeline on the default arithmetics (FP64 + lazy pseudo-Mersenne butterflies through the plain epilogues)
         {"HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_KEYS_UNPACKED": "1"},  # Harvey [0, 4q) butterflies for the 60-bit primes; two inner-product launches
     ]
@@ -305,7 +333,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
                   "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA", "HYDIA_MODUP_PER_DIGIT",
                   "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP", "HYDIA_NTT_NO_PM", "HYDIA_RELIN_TWO_IP_LAUNCHES",
-                  "HYDIA_NO_COLFUSE"):
+                  "HYDIA_NO_COLFUSE", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW", "HYDIA_IP_GROUP", "HYDIA_NTT_GENERIC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

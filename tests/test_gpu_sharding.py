@@ -465,6 +465,21 @@ def test_db_save_load_round_trip(im, tmp_path):
         c3.db_load(path)
     with pytest.raises(im.HydiaError):
         c2.db_load(tmp_path / "missing.hydia")
+    # the header is untrusted input (round-2 review): a ciphertext count that does not follow from the vector count, a truncated
+    # file and trailing bytes are refused BEFORE anything is allocated or the resident database is touched
+    raw = bytearray(path.read_bytes())
+    hdr_ncts = 8 + 6 * 4 + 8   # magic, six u32 fields, n_vectors -> n_cts (u64)
+    assert int.from_bytes(raw[hdr_ncts:hdr_ncts + 8], "little") == stats[1]
+    for name, blob in (("count", raw[:hdr_ncts] + (stats[1] * 1000).to_bytes(8, "little") + raw[hdr_ncts + 8:]),
+                       ("zero", raw[:hdr_ncts] + (0).to_bytes(8, "little") + raw[hdr_ncts + 8:]),
+                       ("vectors", raw[:hdr_ncts - 8] + (1 << 40).to_bytes(8, "little") + raw[hdr_ncts:]),
+                       ("short", raw[:len(raw) - 4096]), ("long", raw + b"\0" * 16)):
+        bad = tmp_path / ("bad_%s.hydia" % name)
+        bad.write_bytes(bytes(blob))
+        with pytest.raises(im.HydiaError):
+            c2.db_load(bad)
+        assert c2.db_stats() == stats, name
+        assert np.array_equal(im.DiagonalSender(c2, n).indexScenario(q2).export(), want), name
     del q, q2
     for c in (cc, c2, c3):
         c.close()

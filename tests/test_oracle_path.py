@@ -110,6 +110,45 @@ def test_compare_guard_and_plain_curve(small_params, small_keys):
         assert np.abs(o - r).max() < TOL
 
 
+def numpy_compare_plain(x, delta, degree):
+    """chebyshevCompare's plain composite (src/openFHE_wrapper.cpp:143-185) with numpy only: Chebyshev interpolation of the step at the
+    degree + 1 Chebyshev nodes (what EvalChebyshevFunction derives), then f4 (:158-169), then + 1"""
+    k = np.arange(degree + 1)
+    nodes = np.cos(np.pi * (k + 0.5) / (degree + 1))
+    f = np.where(nodes >= delta, 1.0, -1.0)
+    c = np.array([2.0 / (degree + 1) * np.sum(f * np.cos(np.pi * j * (k + 0.5) / (degree + 1))) for j in range(degree + 1)])
+    c[0] *= 0.5
+    y = np.polynomial.chebyshev.chebval(x, c)
+    f4 = [0, 315 / 128, 0, -420 / 128, 0, 378 / 128, 0, -180 / 128, 0, 35 / 128]
+    return np.polynomial.polynomial.polyval(y, f4) + 1.0
+
+
+def test_compare_depths_11_to_15(small_params):
+    """The upper half of the reference's DEPTH_TO_DEGREE table (src/openFHE_wrapper.cpp:153-155: depths 11..15 = degrees 119, 247, 495,
+    1007, 2031; approach 5 itself uses depth 10).  (i) the oracle's plain composite equals an independent numpy evaluation of the same
+    construction; (ii) the oracle's ENCRYPTED evaluation on a 16-level chain (reduced ring) agrees with it within the 1e-4 tolerance."""
+    x = np.concatenate([np.linspace(-1, 1, 33), np.linspace(0.40, 0.48, 16)])  # each oracle call re-derives the O(degree^2) coefficients
+    L = O.lib()
+    degrees = {11: 119, 12: 247, 13: 495, 14: 1007, 15: 2031}
+    for depth, degree in degrees.items():
+        got = np.array([L.hyo_compare_plain(float(v), 0.44, degree) for v in x])
+        assert np.abs(got - numpy_compare_plain(x, 0.44, degree)).max() < 1e-6, depth
+    P = O.Params(log_n=11, depth=16, dim=64)
+    K = O.Keys(P, 5, rotations=[])
+    Or = O.Oracle(P, K)
+    xs = np.linspace(-1, 1, P.slots)
+    ct = Or.encrypt(xs, 3, 1)
+    P.L.hyo_drop_to(P.h, ct.h, P.nQ - 1)
+    for depth, degree in degrees.items():
+        out_ct = Or.chebyshev_compare(ct, 0.44, depth)
+        assert out_ct.nl == P.nQ - 1 - depth
+        out = Or.decrypt(out_ct)
+        ref = numpy_compare_plain(xs, 0.44, degree)  # pinned to the oracle's own composite in (i)
+        assert np.abs(out - ref).max() < TOL, depth
+        band = 4.0 / degree + 0.01  # the transition narrows with the degree
+        assert (out[xs < 0.44 - band] < 1.0).all() and (out[xs > 0.44 + band] >= 1.0).all(), depth
+
+
 @pytest.mark.parametrize("n,matches", [(1300, [0, 1299]), (5, [2])])
 def test_hers_path_small_ring(small_params, small_keys, n, matches):
     """Approach 4 (HERS) on the oracle: column packing, one query ciphertext per dimension, relin + rescale per
