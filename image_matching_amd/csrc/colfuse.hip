@@ -162,7 +162,7 @@ DEV void cf_convert(const FpA ar, const ModC &M, const u64 (&f)[HY_CF_SRC], cons
 // grid (8 column tiles, XP polynomials, ncf maps x target slices), 256 threads: col = t & 31, g = t >> 5
 template <bool MDR>
 __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
-                                                           size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz) {
+                                                           size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz, int pre) {
     constexpr int N = 32768;
     extern __shared__ __attribute__((aligned(16))) u64 cf_smem[];
     u64 *const img = cf_smem;  // two exchange images of 128 x 32
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
     const int t = threadIdx.x, col = t & 31, g = t >> 5;
     const int xp = blockIdx.y, c0 = blockIdx.x * 32;
     const u64 *sb = src + (size_t)xp * so + c0 + col;
-    // ---- every global load of the workgroup, up front
+    // ---- every global load of the workgroup, up front.  pre: the sources are already canonical coefficient-form residues (their
+    // inverse transform ran as its own, wider launch: a launch too small to fill the chip keeps its serial chain short that way) —
+    // a lane then loads the rows g + 8k it converts, not the rows 8h + l pass 1' starts from
     u64 y[HY_CF_SRC][16], um[16];
 #pragma unroll
     for (int s = 0; s < HY_CF_SRC; s++)
@@ -184,19 +186,29 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
             for (int k = 0; k < 16; k++) y[s][k] = 0;
         } else {
             const u64 *sp = sb + (size_t)cf.srow[s] * N;
+            if (pre) {
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++)
+                for (int k = 0; k < 16; k++) y[s][k] = sp[(size_t)(g + 8 * k) * 256];
+            } else {
 #pragma unroll
-                for (int l = 0; l < 8; l++) y[s][8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+                for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                    for (int l = 0; l < 8; l++) y[s][8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+            }
         }
     if (MDR) {
         const u64 *sp = sb + (size_t)cf.urow * N;
+        if (pre) {
 #pragma unroll
-        for (int hh = 0; hh < 2; hh++)
+            for (int k = 0; k < 16; k++) um[k] = sp[(size_t)(g + 8 * k) * 256];
+        } else {
 #pragma unroll
-            for (int l = 0; l < 8; l++) um[8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int l = 0; l < 8; l++) um[8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+        }
     }
-    if (t < 128) {
+    if (!pre && t < 128) {
 #pragma unroll
         for (int s = 0; s < HY_CF_SRC; s++)
             if (s < cf.nk) {
@@ -213,11 +225,13 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
     __syncthreads();
     int buf = 0;
     // ---- pass 1' of every source: raw -> canonical coefficient-form residues, in place in y / um
+    if (!pre) {
     if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, img + (buf ^= 1) * 4096, g, col, cf.ssc[0], cf.ssc_sh[0], y[0]);
     if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, img + (buf ^= 1) * 4096, g, col, cf.ssc[1], cf.ssc_sh[1], y[1]);
     if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, img + (buf ^= 1) * 4096, g, col, cf.ssc[2], cf.ssc_sh[2], y[2]);
     if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, img + (buf ^= 1) * 4096, g, col, cf.ssc[3], cf.ssc_sh[3], y[3]);
     if (MDR) cf_inverse_any(T, cf.umod, sltw + HY_CF_SRC * 128, img + (buf ^= 1) * 4096, g, col, cf.usc, cf.usc_sh, um);
+    }
     // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
     unsigned neg = 0;
     if (MDR) {
@@ -269,12 +283,106 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
     }
 }
 
+// The small-launch form (a one-block query's tail: too few polynomials to fill the chip): the sources' inverse transform has run as
+// its own launch, ONE target per workgroup, operands loaded where they are used — nothing is kept for a next target, so the kernel
+// needs a third of the registers (four workgroups per CU, no spills) and its serial chain is one conversion + one pass 1.
+// grid (8 column tiles, XP polynomials, ncf maps x targets)
+template <bool MDR>
+__global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
+                                                           size_t dso, const ColFuse *__restrict__ cfs, int nt_max) {
+    constexpr int N = 32768;
+    __shared__ u64 lds[128 * 32];
+    __shared__ ulonglong2 ltw[128];
+    const int zi = blockIdx.z / nt_max, tt = blockIdx.z - zi * nt_max;
+    const ColFuse &cf = cfs[zi];
+    if (tt >= cf.nt) return;  // workgroup-uniform
+    const int t = threadIdx.x, col = t & 31, g = t >> 5;
+    const int xp = blockIdx.y, c0 = blockIdx.x * 32;
+    const u64 *sb = src + (size_t)xp * so + c0 + col;
+    const int m = cf.tmod[tt];
+    const ModC M = T.mod[m];
+    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
+    if (t < 128) ltw[t] = tw[t];
+    u64 f[HY_CF_SRC], fl[HY_CF_SRC];
+    const u64 *sp[HY_CF_SRC];
+#pragma unroll
+    for (int s = 0; s < HY_CF_SRC; s++) {
+        const bool on = s < cf.nk;
+        f[s] = on ? cf.f[s][tt] : 0;
+        fl[s] = (MDR && on) ? cf.fl[s] : 0;
+        sp[s] = sb + (size_t)cf.srow[on ? s : 0] * N;  // absent sources re-read source 0 against a zero constant
+    }
+    const u64 *su = MDR ? sb + (size_t)cf.urow * N : sb;
+    const ModC Ml = T.mod[MDR ? cf.l : m];
+    u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;
+    // one row at a time: the (up to five) operands of row g + 8k are loaded where they are used; a holds sum_s y_s f_s, the dropped
+    // limb's centred residue (MDR) is formed from the same operands
+    auto convert_row = [&](int k, u128 &a, u64 &mag, bool &ng) {
+        const size_t off = (size_t)(g + 8 * k) * 256;
+        u128 al = 0;
+        a = 0;
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) {
+            const u64 ys = sp[s][off];
+            a += (u128)ys * f[s];
+            if (MDR) al += (u128)ys * fl[s];
+        }
+        mag = 0;
+        ng = false;
+        if (MDR) {
+            const u64 yl = submod(su[off], reduce128k(al, Ml), Ml.q);
+            ng = yl > (Ml.q >> 1);
+            mag = ng ? Ml.q - yl : yl;
+        }
+    };
+    if (fp) {
+        const FpA ar(M);
+        const double c64 = FpA::u2d(0ull - M.r64 * M.q);  // 2^64 mod q (cf_convert's FP64 fold)
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            u128 a;
+            u64 mag;
+            bool ng;
+            convert_row(k, a, mag, ng);
+            const u64 a0 = (u64)a;
+            const double t1 = ar.mulmod2(FpA::u2d((u64)(a >> 64)), c64);
+            const double h = (double)(unsigned)(a0 >> 32) * 4294967296.0;
+            const double t0 = __fma_rn(-rint(h * ar.qinv), ar.q, h);
+            double r = t1 + t0 + (double)(unsigned)a0;
+            if (MDR) r += ng ? -FpA::u2d(mag) : FpA::u2d(mag);
+            v[k] = r;
+        }
+        cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
+    } else {
+        u64 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            u128 a;
+            u64 mag;
+            bool ng;
+            convert_row(k, a, mag, ng);
+            u64 r = reduce128k(a, M);
+            if (MDR) {
+                const u64 c = reduce64(mag, M);
+                r = addmod(r, ng ? negmod(c, M.q) : c, M.q);
+            }
+            v[k] = r;
+        }
+        if ((T.pm_mask >> m) & 1u) cf_forward<IntP>(IntP(M), tw, ltw, lds, g, col, v, d);
+        else cf_forward<IntA>(IntA(M), tw, ltw, lds, g, col, v, d);
+    }
+}
+
 }  // namespace
 
 namespace hk {
 
+bool ntt15_colfuse_small(int XP, int ncf) { return 8 * XP * ncf < 256; }
+
 void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
-                   const ColFuse *h_cf, int ncf) {
+                   const ColFuse *h_cf, int ncf, bool pre) {
     static bool attr_done[64][2] = {};  // > 64 KiB of dynamic LDS has to be granted per kernel and per device
     const bool mdr = h_cf[0].mdr != 0;
     int dev = 0;
@@ -290,18 +398,24 @@ void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so
         nt_max = std::max(nt_max, h_cf[i].nt);
         rows += h_cf[i].nk + (h_cf[i].mdr ? 1 : 0) + h_cf[i].nt;
     }
+    if (pre) {  // small launch: one target per workgroup, the light kernel
+        ledger_add(mdr ? "k_ntt15_conv_p1<true>" : "k_ntt15_conv_p1<false>", rows * XP * 262144.0);
+        if (mdr) hipLaunchKernelGGL((k_ntt15_conv_p1<true>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
+        else hipLaunchKernelGGL((k_ntt15_conv_p1<false>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
+        return;
+    }
     ledger_add(mdr ? "k_ntt15_colfuse<true>" : "k_ntt15_colfuse<false>", rows * XP * 262144.0);
-    // launches that cannot fill the chip (a one-block query's tail) slice their targets over grid.z: every slice repeats the sources'
-    // inverse transforms (from L2) and serves tz targets, so the serial chain per workgroup shrinks with the launch
+    // launches that cannot fill the chip (a one-block query's tail) slice their targets over grid.z: every slice re-reads the sources
+    // (from L2) and serves tz targets, so the serial chain per workgroup shrinks with the launch
     const int base = 8 * XP * ncf;
     int slices = 1;
     if (base < 512) slices = std::min(nt_max, (512 + base - 1) / base);
     const int tz = (nt_max + slices - 1) / slices;
     slices = (nt_max + tz - 1) / tz;
     if (mdr)
-        hipLaunchKernelGGL((k_ntt15_colfuse<true>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz);
+        hipLaunchKernelGGL((k_ntt15_colfuse<true>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz, pre ? 1 : 0);
     else
-        hipLaunchKernelGGL((k_ntt15_colfuse<false>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz);
+        hipLaunchKernelGGL((k_ntt15_colfuse<false>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz, pre ? 1 : 0);
 }
 
 }  // namespace hk

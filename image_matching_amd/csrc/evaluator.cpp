@@ -187,8 +187,10 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
     if (cf_ok()) {
         // inverse pass 2' of every limb, then ONE column-fused launch: pass 1' of a digit's limbs, conversion, pass 1 of its targets
         const CfPlan &cp = cf_plan_modup(nl);
-        hk::ntt15_inverse_p2(stream, tabs, c, y, c_outer, (size_t)nl * N, X, qsel);
-        hk::ntt15_colfuse(stream, tabs, y, (size_t)nl * N, dig, dig_x, X, cp.dev, cp.host.data(), nd);
+        const bool small = hk::ntt15_colfuse_small(X, nd);  // few workgroups: the inverse transform as its own (wider) launch
+        if (small) ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
+        else hk::ntt15_inverse_p2(stream, tabs, c, y, c_outer, (size_t)nl * N, X, qsel);
+        hk::ntt15_colfuse(stream, tabs, y, (size_t)nl * N, dig, dig_x, X, cp.dev, cp.host.data(), nd, small);
         pool.put(y);
         if (!p1_only) {
             if ((size_t)X * nd * nE < 128) {  // small launch: one second pass over every row (the own rows hold garbage nobody reads)
@@ -335,8 +337,10 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     if (cf_ok()) {
         // special-prime limbs: pass 2' alone, then pass 1' + conversion + pass 1 in one column-fused launch, then pass 2 + ModDown combine
         const CfPlan &cp = cf_plan_moddown(nl, false);
-        hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel);
-        hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, cp.dev, cp.host.data(), 1);
+        const bool small = hk::ntt15_colfuse_small(X * 2, 1);
+        if (small) ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
+        else hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel);
+        hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, cp.dev, cp.host.data(), 1, small);
         NttStore stp{};
         stp.mode = 1;
         stp.out = out;
@@ -557,11 +561,12 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
         tail_scale[1 + k] = Phat_inv[k];
     }
     const bool cfu = cf_ok() && (q[l] >> 50) == 0;  // the fused kernel carries the dropped limb's centred residue as a double
+    const bool cf_pre = cfu && hk::ntt15_colfuse_small(XP, 1);  // few workgroups: pass 1' as its own (wider) launch
     if (fused_tail) {
         hk::ntt15_inverse_p2_last_limb(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
                                        c.d, c.ct_elems(), c.poly_elems(), dbl ? 1 : 0);
-        if (!cfu) hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
-    } else if (cfu) {
+        if (!cfu || cf_pre) hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
+    } else if (cfu && !cf_pre) {
         hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail);
     } else {
         ntt_inv(acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
@@ -579,7 +584,7 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     u64 *w = pool.get((size_t)XP * l * N * sizeof(u64));
     if (cfu) {  // pass 1' of u and the special-prime limbs, the correction of every remaining limb and its pass 1: one launch
         const CfPlan &cp = cf_plan_moddown_rescale(nl, dbl);
-        hk::ntt15_colfuse(stream, tabs, yu, yu_outer, w, (size_t)l * N, XP, cp.dev, cp.host.data(), 1);
+        hk::ntt15_colfuse(stream, tabs, yu, yu_outer, w, (size_t)l * N, XP, cp.dev, cp.host.data(), 1, cf_pre);
     } else {
         hk::moddown_rescale_conv(stream, d_mod, N, y, yu_outer, u, yu_outer, w, XP, l, nP, tab);
     }

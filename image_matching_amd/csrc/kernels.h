@@ -267,8 +267,11 @@ void ntt15_forward_p2(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, 
 void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const NttStore &stp);
 // column-fused conversion: src [XP][..][N] holds the raw image of the sources' inverse pass 2', dst [XP][..][N] receives the raw
 // pass-1 image of the targets (pass 2 finishes it).  d_cf: ncf maps in device memory (h_cf: host copy), map z serves every polynomial
+// pre: src holds the sources' canonical coefficient-form residues (inverse transform already complete) — the form small launches
+// take (ntt15_colfuse_small): their inverse transform runs as its own, wider launch and the fused kernel keeps a short serial chain
 void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
-                   const ColFuse *h_cf, int ncf);
+                   const ColFuse *h_cf, int ncf, bool pre = false);
+bool ntt15_colfuse_small(int XP, int ncf);
 // out[x][p][j][c'] = ((acc[x][p][j][c] - conv[x][p][j][c]) * pinv[j] + (addend ? addend[x*add_x + p*add_ps + j*N + c] : 0)),
 // c = perm_g(c') when galois[x] != 1 (evaluation-form automorphism), acc rows have stride acc_limbs*N
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,
