@@ -110,7 +110,7 @@ def cpu_baseline():
     S, n3 = P.slots, 3 * P.slots
     planted = [5, S + 9, n3 - 1]
     db = synth_rows(0, n3, P.dim, planted)
-    dbc = Or.enroll(db, 99)
+    dbc = Or.enroll(db, 99, matvec="hoisted")  # the reference's own algorithm (sender_diag.cpp:22-26), whatever form the GPU run chose
     q = Or.encrypt_query(np.ones(P.dim), 5, 1)
 
     def timed(fn):
@@ -363,12 +363,17 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         nl, N = cc.nQ, cc.N
-        algo_bytes = (G_local * dim + dim) * 2 * nl * N * 8 + G_local * 3 * nl * N * 8
+        bsgs = cc.db_kind() == 6
+        # loop B's operands: the database once, the rotated queries once, the degree-2 accumulators once.  Hoisted form: dim rotated
+        # queries, one accumulator per block; baby-step / giant-step form: B = 32 babies, dim / B accumulators per block
+        n_rot = cc.bsgs_babies() if bsgs else dim
+        n_acc = G_local * (dim // n_rot if bsgs else 1)
+        algo_bytes = (G_local * dim + n_rot) * 2 * nl * N * 8 + n_acc * 3 * nl * N * 8
         avg_launch_s = ms_tensor / max(launches, 1) / 1e3
         achieved = algo_bytes / avg_launch_s / 1e9 if launches else 0.0
         # bytes the kernel has to move given the RESIDENT layout (48-bit residues for the 45/46-bit limbs of the database;
         # rotated queries and accumulators at 8 bytes): what the wire sees when nothing is read twice
-        resident_bytes = db_resident_bytes + dim * 2 * nl * N * 8 + G_local * 3 * nl * N * 8
+        resident_bytes = db_resident_bytes + n_rot * 2 * nl * N * 8 + n_acc * 3 * nl * N * 8
         wire = resident_bytes / avg_launch_s / 1e9 if launches else 0.0
         traffic = traffic_meta = None
         tpath = os.path.join(ROOT, "profiles", "tensor_traffic.json")
@@ -399,6 +404,10 @@ def main():
                                    % (G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30),
                        "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
+                       "matvec": ("baby-step / giant-step: %d hoisted rotations of the query, %d relinearised partial sums per block rotated by "
+                                  "multiples of %d (pre-rotated diagonals; chosen because this GPU holds <= %d blocks)"
+                                  % (n_rot - 1, dim // n_rot, n_rot, im.bsgs_max_blocks())) if bsgs else
+                                 "hoisted: %d hoisted rotations of the query, one relinearisation per block (the reference's form)" % (dim - 1),
                        "sharding": "row-blocks per GPU (image_matching_amd.sharding.DistDiagonalSender): query broadcast, loop A %s, "
                                    "independent mat-vec per rank, RCCL gather of result ciphertexts in global block order"
                                    % ("shared out over the ranks and all-gathered" if (loop_a and loop_a["mode"] == "split") else "recomputed by every rank")

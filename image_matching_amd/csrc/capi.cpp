@@ -461,32 +461,45 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     }
     cx.sync();
     cx.pool.put(tmp);
-    cx.db_kind = 5;
+    cx.db_kind = cx.want_bsgs((n_vectors + (size_t)cx.slots - 1) / (size_t)cx.slots) ? 6 : 5;  // random residues: either form's cost model
     return HYDIA_OK;
     API_END
 }
-int hydia_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
+// matvec: 0 = the context's own policy (hydia_set_matvec; auto by the blocks THIS context holds), 1 hoisted, 2 bsgs — a sharded
+// enrolment passes the group-wide decision so that every shard of one database uses the same form
+int hydia_db_enroll_shard_ex(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block, int matvec) {
     API_BEGIN
     use_device(ctx);
-    REQUIRE(ctx && db && seed && n >= 1, "bad argument");
+    REQUIRE(ctx && db && seed && n >= 1 && matvec >= 0 && matvec <= 2, "bad argument");
     Context &cx = ctx->cx;
+    const size_t G = (n + (size_t)cx.slots - 1) / (size_t)cx.slots;
+    const bool bsgs = matvec == 2 || (matvec == 0 && cx.want_bsgs(G));
+    cx.db_kind = 0;
     cx.db_resize(n, hydia_db_num_cts(ctx, n));
-    client_enroll(cx, db, n, seed);
-    cx.db_kind = 5;
+    client_enroll(cx, db, n, seed, first_block, bsgs);
+    cx.db_kind = bsgs ? 6 : 5;
     return HYDIA_OK;
     API_END
 }
+int hydia_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) { return hydia_db_enroll_shard_ex(ctx, db, n, seed, 0, 0); }
 int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block) {
-    API_BEGIN
-    use_device(ctx);
-    REQUIRE(ctx && db && seed && n >= 1, "bad argument");
-    Context &cx = ctx->cx;
-    cx.db_resize(n, hydia_db_num_cts(ctx, n));
-    client_enroll(cx, db, n, seed, first_block);
-    cx.db_kind = 5;
-    return HYDIA_OK;
-    API_END
+    return hydia_db_enroll_shard_ex(ctx, db, n, seed, first_block, 0);
 }
+int hydia_set_matvec(hydia_ctx *ctx, int mode) {
+    REQUIRE(ctx && mode >= 0 && mode <= 2, "mat-vec mode is 0 (auto), 1 (hoisted) or 2 (bsgs)");
+    ctx->cx.matvec_mode = mode;
+    return HYDIA_OK;
+}
+/* which form the ciphertexts of an imported database are in (hydia_db_alloc + hydia_db_import_ct assume 5, the reference enroller's) */
+int hydia_db_set_kind(hydia_ctx *ctx, int kind) {
+    REQUIRE(ctx && (kind == 5 || kind == 6), "database kind is 5 (hoisted diagonals) or 6 (pre-rotated diagonals)");
+    if (!ctx->cx.d_db || ctx->cx.db_cts == 0 || ctx->cx.db_kind == 4) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
+    ctx->cx.db_kind = kind;
+    return HYDIA_OK;
+}
+int hydia_get_matvec(const hydia_ctx *ctx) { return ctx ? ctx->cx.matvec_mode : -1; }
+int hydia_db_kind(const hydia_ctx *ctx) { return ctx ? ctx->cx.db_kind : 0; }
+size_t hydia_bsgs_max_blocks(void) { return HY_BSGS_MAX_BLOCKS; }
 int hydia_hers_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
     API_BEGIN
     use_device(ctx);

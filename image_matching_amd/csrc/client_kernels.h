@@ -35,7 +35,7 @@ void encode(hipStream_t st, const double *slots, double2 *work, long long *coeff
             const unsigned *rot_group, const double2 *ksi);
 void decode(hipStream_t st, const ModC *mod, const u64 *t, int nu, int N, int X, double scale, u64 q0inv_mod_q1,
             double2 *work, double *out, const unsigned *rot_group, const double2 *ksi);
-void diag_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots);
+void diag_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots, int babies = 0);
 // HERS (approach 4): slots[j][k] = dbg[k][j] (column packing); query coordinate i broadcast to every slot of vector i
 void hers_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots);
 void broadcast_rows(hipStream_t st, const double *vals, int dim, int Nh, double *slots);

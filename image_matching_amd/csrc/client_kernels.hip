@@ -255,12 +255,15 @@ __global__ __launch_bounds__(256) void k_complex_real(const double2 *__restrict_
 // DiagonalEnroller's splitIntoSquareMatrices + preprocessToDiagonalForm + concatenateRows for ONE ciphertext group g:
 // slots[i][j*dim + r] = db[(g*per + j)*dim + r][(r + i) mod dim] (0 beyond n).  dbg points at row g*per*dim.
 // grid (slots/256, dim)
+// babies > 0 (baby-step / giant-step form of the mat-vec): diagonal i is rotated by -babies * (i / babies) slots in the clear, i.e. output
+// slot s takes what the plain layout has in slot s - babies * (i / babies) (mod Nh)
 __global__ __launch_bounds__(256) void k_diag_pack(const double *__restrict__ dbg, long long rows_left, int dim, int Nh,
-                                                   double *__restrict__ slots) {
-    const int s = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+                                                   double *__restrict__ slots, int babies) {
+    const int so = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    const int s = babies > 0 ? (so + Nh - (babies * (i / babies)) % Nh) % Nh : so;
     const int r = s % dim;
     const long long v = s;  // row inside this group = j*dim + r = s
-    slots[(size_t)i * Nh + s] = v < rows_left ? dbg[(size_t)v * dim + (r + i) % dim] : 0.0;
+    slots[(size_t)i * Nh + so] = v < rows_left ? dbg[(size_t)v * dim + (r + i) % dim] : 0.0;
 }
 
 // HersEnroller::serializeDBThread (/root/reference/src/enroller/enroller_hers.cpp:108-113): slots[j][k] = db[m*S + k][j].
@@ -342,8 +345,8 @@ void hers_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, 
 void broadcast_rows(hipStream_t st, const double *vals, int dim, int Nh, double *slots) {
     hipLaunchKernelGGL(k_broadcast_rows, dim3(Nh / 256, dim), dim3(256), 0, st, vals, Nh, slots);
 }
-void diag_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots) {
-    hipLaunchKernelGGL(k_diag_pack, dim3(Nh / 256, dim), dim3(256), 0, st, dbg, rows_left, dim, Nh, slots);
+void diag_pack(hipStream_t st, const double *dbg, long long rows_left, int dim, int Nh, double *slots, int babies) {
+    hipLaunchKernelGGL(k_diag_pack, dim3(Nh / 256, dim), dim3(256), 0, st, dbg, rows_left, dim, Nh, slots, babies);
 }
 
 }  // namespace hc

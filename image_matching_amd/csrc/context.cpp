@@ -371,6 +371,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
     fuse_loop_a = getenv("HYDIA_NO_FUSE_LOOPA") == nullptr;
     colfuse = getenv("HYDIA_NO_COLFUSE") == nullptr;
+    if (const char *e = getenv("HYDIA_MATVEC")) matvec_mode = e[0] == 'h' ? 1 : e[0] == 'b' ? 2 : 0;
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)
@@ -402,7 +403,7 @@ Context::~Context() {
                 if (p) (void)hipFree(p);
     if (keys_borrowed) d_rotpack = nullptr, d_sk = nullptr, d_pk = nullptr;
     for (void *p : {(void *)d_mod, (void *)d_tw, (void *)d_tw_sh, (void *)d_itw, (void *)d_itw_sh, (void *)d_twp, (void *)d_itwp, (void *)d_twf, (void *)d_itwf, (void *)d_twd, (void *)d_itwd,
-                    (void *)d_rotptrs, (void *)d_rotpack,
+                    (void *)d_rotptrs, (void *)d_rotpack, (void *)d_giant_keys, (void *)d_giant_gal, (void *)d_giant_ginv,
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     for (auto e : lane_ev) (void)hipEventDestroy(e);
@@ -508,7 +509,7 @@ u64 *Context::eval_key_storage(int rot) {
     }
     // every caller is about to WRITE this key (import, key generation, random fill): loop A's pointer table and its packed
     // shadow of rotations 1..dim-1 are rebuilt from the new contents before the next query
-    if (rot >= 1 && rot < prm.dim) rotptrs_valid = false;
+    if (rot >= 1 && rot < prm.dim) rotptrs_valid = giants_valid = false;
     return k.d;
 }
 void Context::load_eval_key(int rot, const u64 *host) {
@@ -578,14 +579,14 @@ void Context::db_load(const char *path) {
         if (h.moduli[j] != q[j]) throw std::runtime_error("hydia: database file was written on another prime chain");
     if ((h.packed != 0) != db_packed || h.ct_bytes != db_layout().ct_bytes)
         throw std::runtime_error("hydia: database file layout (48-bit packed / 8-byte) differs from this context's");
-    if (h.kind != 4 && h.kind != 5) throw std::runtime_error("hydia: database file has an unknown packing kind");
+    if (h.kind != 4 && h.kind != 5 && h.kind != 6) throw std::runtime_error("hydia: database file has an unknown packing kind");
     // the header is untrusted input: the ciphertext count must be the one the packing implies for n_vectors (diagonal packing:
     // ceil(ceil(n / dim) / (slots / dim)) * dim; column packing: ceil(n / slots) * dim), and the file must hold exactly that many
     // — checked BEFORE anything is allocated or the resident database is touched
     if (h.n_vectors < 1 || h.n_cts < 1) throw std::runtime_error("hydia: database file header declares an empty database");
     const uint64_t dim = (uint64_t)prm.dim, S = (uint64_t)slots;
     const uint64_t G = (h.n_vectors + S - 1) / S;
-    const uint64_t want_cts = h.kind == 5 ? (((h.n_vectors + dim - 1) / dim + S / dim - 1) / (S / dim)) * dim : G * dim;
+    const uint64_t want_cts = h.kind != 4 ? (((h.n_vectors + dim - 1) / dim + S / dim - 1) / (S / dim)) * dim : G * dim;
     if (h.n_vectors > (UINT64_MAX - S) || h.n_cts != want_cts)
         throw std::runtime_error("hydia: database file header is inconsistent (ciphertext count does not match the vector count)");
     {

@@ -785,9 +785,85 @@ void Context::rotate_query_range(const Ct &qc, int first, int count, u64 *out) {
 }
 // computeSimilarity (sender_diag.cpp:12-33): all G blocks of the resident DB in one tensor-accumulate launch
 Ct Context::similarity(const Ct &qc) {
+    if (db_kind == 6) {
+        Ct sum = similarity_bsgs_sum(qc);
+        rescale(sum);
+        return sum;
+    }
     Ct acc = similarity_accumulate(qc);
     relin_rescale(acc);
     return acc;
+}
+
+// ------------------------------------------------------------------ baby-step / giant-step form of the mat-vec (north_star)
+// With i = b + B g (B babies, NG = dim / B giants) and Rot_i = Rot_{Bg} o Rot_b:
+//     sum_i Rot_i(q) . db_i  =  sum_g Rot_{Bg}( sum_b Rot_b(q) . Rot_{-Bg}(db_{b + Bg}) )
+// and the enroller has rotated diagonal i by -B (i div B) in the clear (database kind 6; same ciphertext order, so the inner sums
+// are loop B's own kernel on NG G "blocks" of B diagonals).  Per query B - 1 hoisted rotations instead of dim - 1; per block NG
+// relinearisations and NG - 1 ordinary rotations (rotation keys B, 2B, ..: already part of the key set) instead of one
+// relinearisation — the better trade while a GPU holds few blocks (Context::want_bsgs).  The reference itself hoists every
+// rotation (sender_diag.cpp:22-26); SURVEY "fact 2" allows this form as long as decrypted scores stay within 1e-4, and the oracle
+// restates it (oracle/path.c hyo_compute_similarity_bsgs) so the ciphertexts are still checked bit for bit.
+void Context::build_giants() {
+    if (giants_valid) return;
+    const int B = bsgs_babies(), NG = (prm.dim + B - 1) / B;
+    std::vector<const u64 *> ptrs(NG, nullptr);
+    std::vector<unsigned> gal(NG, 1u), ginv(NG, 1u);
+    for (int g = 1; g < NG; g++) {
+        auto it = rot_keys.find(g * B);
+        if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(g * B) + " not loaded");
+        ptrs[g] = it->second.d;
+        gal[g] = (unsigned)galois_elt(g * B);
+        u64 x = 1;
+        for (int k = 0; k < 6; k++) x = x * (2 - (u64)gal[g] * x);
+        ginv[g] = (unsigned)(x & (2ull * N - 1));
+    }
+    if (!d_giant_keys) {
+        HIP_CHECK(hipMalloc((void **)&d_giant_keys, sizeof(u64 *) * NG));
+        HIP_CHECK(hipMalloc((void **)&d_giant_gal, sizeof(unsigned) * NG));
+        HIP_CHECK(hipMalloc((void **)&d_giant_ginv, sizeof(unsigned) * NG));
+    }
+    sync_all();
+    HIP_CHECK(hipMemcpy((void *)d_giant_keys, ptrs.data(), sizeof(u64 *) * NG, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_giant_gal, gal.data(), sizeof(unsigned) * NG, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_giant_ginv, ginv.data(), sizeof(unsigned) * NG, hipMemcpyHostToDevice));
+    giants_valid = true;
+}
+Ct Context::similarity_bsgs_sum(const Ct &qc) {
+    if (!d_db || db_cts == 0 || db_kind != 6) throw StateError("hydia: no database resident (pre-rotated diagonal packing)");
+    if (qc.nl != nQ) throw StateError("hydia: query must be a fresh (level 0) ciphertext");
+    const int dim = prm.dim, B = bsgs_babies(), NG = (dim + B - 1) / B;
+    if (dim % B) throw std::runtime_error("hydia: the baby-step / giant-step mat-vec needs vector_dim to be a multiple of the baby count");
+    const int G = (int)(db_cts / dim), nl = nQ, nE = nl + nP, nd = (nl + alpha - 1) / alpha;
+    build_giants();
+    // babies: rotations 0 .. B-1 of the query (loop A on B - 1 keys)
+    Ct rot(this, B, 2, nl, qc.scale);
+    rotate_query_range(qc, 0, B, rot.d);
+    // inner sums: ciphertext t = (block*NG + g)*B + b is "diagonal b of block block*NG + g"
+    Ct acc(this, G * NG, 3, nl, qc.scale * delta);
+    timer_begin("hydia_tensor");
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G * NG, B, nl, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
+    timer_end("hydia_tensor");
+    relinearize(acc);  // [G*NG][2][nl]
+    // giant steps: per block the partial sums g >= 1 go through ONE batched key switch with rotation key B g each (the
+    // automorphism rides in the ModDown epilogue), land next to the unrotated g = 0 sum and are added up
+    Ct out(this, G, 2, nl, acc.scale);
+    Ct part(this, NG, 2, nl, acc.scale);
+    u64 *dig = NG > 1 ? pool.get((size_t)(NG - 1) * nd * nE * N * sizeof(u64)) : nullptr;
+    const size_t ce = acc.ct_elems();
+    for (int m = 0; m < G; m++) {
+        const u64 *base = acc.d + (size_t)m * NG * ce;
+        HIP_CHECK(hipMemcpyAsync(part.d, base, ce * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+        if (NG > 1) {
+            const u64 *c = base + ce;  // partial sums g = 1 ..
+            modup_digits(c + acc.poly_elems(), ce, NG - 1, nl, dig);
+            ks_apply(dig, (size_t)nd * nE * N, NG - 1, nl, d_giant_keys + 1, 0, c, ce, acc.poly_elems(), 1, d_giant_gal + 1,
+                     d_giant_ginv + 1, 0, false, part.d + ce);
+        }
+        hk::batch_sum(stream, d_mod, N, part.d, out.d + (size_t)m * ce, NG, 2, nl);
+    }
+    if (dig) pool.put(dig);
+    return out;
 }
 
 // ------------------------------------------------------------------ comparator
@@ -1075,8 +1151,10 @@ Ct Context::chebyshev_compare(const Ct &x, double dlt, int sign_depth) {
 // another's (loop B itself stays alone on the main stream).  Same arithmetic per ciphertext whatever the split.
 Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
     const int G = acc.X, L = std::min(nlanes, G);
+    const bool relin = acc.npoly == 3;  // the BSGS mat-vec hands over relinearised sums: only the rescale is left
     if (L <= 1) {
-        relin_rescale(acc);
+        if (relin) relin_rescale(acc);
+        else rescale(acc);
         return chebyshev_compare(acc, dlt, sign_depth);
     }
     while ((int)lane_ev.size() < nlanes + 1) {  // created once, re-recorded per call
@@ -1105,7 +1183,8 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
         Ct part = acc.alias(acc.nl);
         part.X = g1 - g0;
         part.d = acc.d + (size_t)g0 * acc.ct_elems();
-        relin_rescale(part);
+        if (relin) relin_rescale(part);
+        else rescale(part);
         res[k] = chebyshev_compare(part, dlt, sign_depth);
         if (k == 0) {
             out = Ct(this, G, res[0].npoly, res[0].nl, res[0].scale);
@@ -1152,7 +1231,7 @@ Ct Context::index_scenario_rot(const Ct &rot) {
 }
 // indexScenario (sender_diag.cpp:52-63): loop A, loop B, then the per-block tails on the comparator lanes
 Ct Context::index_scenario(const Ct &qc) {
-    Ct acc = similarity_accumulate(qc);
+    Ct acc = db_kind == 6 ? similarity_bsgs_sum(qc) : similarity_accumulate(qc);  // 2 components (relinearised) : 3
     return relin_compare_lanes(acc, 0.44 /* MATCH_THRESHOLD, include/config.h:9 */, 10 /* COMP_DEPTH, :14 */);
 }
 // membershipScenario (sender_diag.cpp:35-50): EvalAddManyInPlace over blocks, then EvalSum over all slots

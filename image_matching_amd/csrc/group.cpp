@@ -28,6 +28,7 @@ struct hydia_group {
     std::vector<size_t> blk_lo, blk_hi;  // block range of each shard of the resident database
     size_t n_vectors = 0, n_blocks = 0;
     bool rot_split = true;  // loop A's rotations shared out over the active shards and exchanged (hydia_group_set_rotation_split)
+    bool bsgs = false;      // the resident database is in the baby-step / giant-step form: B - 1 rotations per query, nothing to share out
 };
 
 namespace {
@@ -154,7 +155,7 @@ int sharded_blocks_call(hydia_group *g, const hydia_ct *query, hydia_ct **out, F
     const std::vector<uint32_t> act = active(g);
     std::vector<Ct> qs = broadcast_query(g, act, query->c);
     std::vector<Ct> res(g->shard.size());
-    if (g->rot_split && act.size() > 1) {
+    if (g->rot_split && !g->bsgs && act.size() > 1) {
         std::vector<Ct> rot = split_rotations(g, act, qs);
         on_shards(g, act, [&](uint32_t r) {
             Context &cx = g->shard[r]->cx;
@@ -302,6 +303,12 @@ int hydia_group_db_enroll(hydia_group *g, double *db, size_t n, const uint8_t se
     g->n_blocks = G;
     std::vector<uint32_t> all(R);
     for (uint32_t r = 0; r < R; r++) all[r] = r;
+    // ONE form of the mat-vec for the whole database (shard 0's policy; auto looks at the LARGEST shard), so the shards' results
+    // are the ciphertexts a single context of that form computes
+    size_t max_blocks = 0;
+    for (uint32_t r = 0; r < R; r++) max_blocks = std::max(max_blocks, g->blk_hi[r] - g->blk_lo[r]);
+    const bool bsgs = g->shard[0]->cx.want_bsgs(max_blocks);
+    g->bsgs = bsgs;
     on_shards(g, all, [&](uint32_t r) {
         Context &cx = g->shard[r]->cx;
         const size_t first = g->blk_lo[r] * S, last = std::min(g->blk_hi[r] * S, n);
@@ -313,8 +320,8 @@ int hydia_group_db_enroll(hydia_group *g, double *db, size_t n, const uint8_t se
         const size_t nl = last - first;
         const size_t per = S / dim, nblk = (nl + dim - 1) / dim;
         cx.db_resize(nl, ((nblk + per - 1) / per) * dim);
-        client_enroll(cx, db + first * dim, nl, seed, g->blk_lo[r]);
-        cx.db_kind = 5;
+        client_enroll(cx, db + first * dim, nl, seed, g->blk_lo[r], bsgs);
+        cx.db_kind = bsgs ? 6 : 5;
     });
     return HYDIA_OK;
     API_END
@@ -341,7 +348,7 @@ int hydia_group_membership_scenario(hydia_group *g, const hydia_ct *query, hydia
     std::vector<Ct> qs = broadcast_query(g, act, query->c);
     std::vector<Ct> part(g->shard.size());
     std::vector<Ct> rot;
-    const bool split = g->rot_split && act.size() > 1;
+    const bool split = g->rot_split && !g->bsgs && act.size() > 1;
     if (split) rot = split_rotations(g, act, qs);
     on_shards(g, act, [&](uint32_t r) {
         Context &cx = g->shard[r]->cx;

@@ -23,6 +23,8 @@ struct StateError : std::runtime_error {   // missing key / database / wrong lev
 };
 }  // namespace hydia
 
+#define HY_BSGS_MAX_BLOCKS 4
+
 #define HIP_CHECK(expr)                                                                                   \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \
@@ -156,7 +158,23 @@ struct Context : HostParams {
     // 48-bit residues when every scaling prime is below 2^48; HYDIA_DB_UNPACKED keeps plain [2][nQ][N] u64)
     unsigned char *d_db = nullptr;
     size_t db_vectors = 0, db_cts = 0;
-    int db_kind = 0;   // 0 none, 5 diagonal packing (HyDia, approach 5), 4 column packing (HERS, approach 4)
+    int db_kind = 0;   // 0 none, 5 diagonal packing (HyDia, approach 5), 6 the same with pre-rotated diagonals (BSGS mat-vec), 4 column packing (HERS)
+    // Which form of the diagonal mat-vec a database enrolled on this context gets (HYDIA_MATVEC=auto|hoisted|bsgs, hydia_set_matvec):
+    //   hoisted  the reference's: dim - 1 hoisted rotations of the query, one tensor-accumulate over all diagonals of a block
+    //   bsgs     baby-step / giant-step (north_star): B - 1 hoisted rotations, dim / B relinearisations + giant rotations per block
+    //   auto     bsgs while this context holds at most HY_BSGS_MAX_BLOCKS blocks (the per-block giant steps then cost less than the
+    //            per-query babies they save), hoisted above
+    int matvec_mode = 0;  // 0 auto, 1 hoisted, 2 bsgs
+    bool want_bsgs(size_t blocks) const { return matvec_mode == 2 || (matvec_mode == 0 && blocks >= 1 && blocks <= HY_BSGS_MAX_BLOCKS); }
+    int bsgs_babies() const {
+        int B = 1;
+        while (B * B < prm.dim) B <<= 1;
+        return B;
+    }
+    const u64 **d_giant_keys = nullptr;  // device arrays over g = 0 .. dim/B - 1: key, Galois element and inverse of rotation B g
+    unsigned *d_giant_gal = nullptr, *d_giant_ginv = nullptr;
+    bool giants_valid = false;
+    void build_giants();
     bool db_packed = true;
     DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }
     void db_resize(size_t n_vectors, size_t cts);         // (re)allocates the resident layout for `cts` ciphertexts
@@ -256,6 +274,7 @@ struct Context : HostParams {
     void rotate_query_range(const Ct &q, int first, int count, u64 *out);
     Ct similarity(const Ct &q);                     // -> [G][2][nQ-1][N]
     // the same scenarios on rotations supplied by the caller ([dim][2][nQ][N], as rotate_query returns them)
+    Ct similarity_bsgs_sum(const Ct &q);            // BSGS mat-vec up to (not including) the rescale: [G][2][nQ][N]
     Ct similarity_accumulate_rot(const Ct &rot);
     Ct similarity_rot(const Ct &rot);
     Ct index_scenario_rot(const Ct &rot);

@@ -113,6 +113,12 @@ def load_library():
         "hydia_ct_add_raw": (i32, [vp, vp, vp, i32]),
         "hydia_ct_mod_reduce": (i32, [vp, vp]),
         "hydia_db_enroll_shard": (i32, [vp, vp, sz, vp, sz]),
+        "hydia_db_enroll_shard_ex": (i32, [vp, vp, sz, vp, sz, i32]),
+        "hydia_set_matvec": (i32, [vp, i32]),
+        "hydia_get_matvec": (i32, [vp]),
+        "hydia_db_kind": (i32, [vp]),
+        "hydia_db_set_kind": (i32, [vp, i32]),
+        "hydia_bsgs_max_blocks": (sz, []),
         "hydia_random_seed": (i32, [vp]),
         "hydia_shard_blocks": (None, [sz, u32, u32, C.POINTER(sz), C.POINTER(sz)]),
         "hydia_group_create": (i32, [C.POINTER(_Params), C.POINTER(i32), u32, pp]),
@@ -192,6 +198,11 @@ def default_params(**over):
     for k, v in over.items():
         setattr(p, k, v)
     return p
+
+
+def bsgs_max_blocks():
+    """blocks per context up to which "auto" picks the baby-step / giant-step mat-vec"""
+    return int(load_library().hydia_bsgs_max_blocks())
 
 
 def compute_required_depth(approach):
@@ -461,6 +472,33 @@ class Context:
     def db_load(self, path):
         _chk(self.L.hydia_db_load(self.h, str(path).encode()))
 
+    # ---- the two forms of the diagonal mat-vec (include/hydia.h): "auto" | "hoisted" | "bsgs"; takes effect at the next enrolment
+    MATVEC = {"auto": 0, "hoisted": 1, "bsgs": 2}
+
+    def set_matvec(self, mode):
+        _chk(self.L.hydia_set_matvec(self.h, self.MATVEC[mode] if isinstance(mode, str) else int(mode)))
+
+    def get_matvec(self):
+        return {v: k for k, v in self.MATVEC.items()}[self.L.hydia_get_matvec(self.h)]
+
+    def db_kind(self):
+        """0 none, 5 hoisted diagonals, 6 pre-rotated diagonals (baby-step / giant-step), 4 HERS columns"""
+        return int(self.L.hydia_db_kind(self.h))
+
+    def bsgs_babies(self):
+        B = 1
+        while B * B < self.dim:
+            B *= 2
+        return B
+
+    def db_set_kind(self, kind):
+        _chk(self.L.hydia_db_set_kind(self.h, int(kind)))
+
+    def want_bsgs(self, blocks):
+        """what an enrolment of `blocks` 16384-vector blocks on this context would choose"""
+        m = self.L.hydia_get_matvec(self.h)
+        return m == 2 or (m == 0 and 1 <= blocks <= int(self.L.hydia_bsgs_max_blocks()))
+
     def db_stats(self):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
         _chk(self.L.hydia_db_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
@@ -492,13 +530,15 @@ class DiagonalEnroller:
     def __init__(self, cc, num_vectors):
         self.cc, self.numVectors = cc, num_vectors
 
-    def serializeDB(self, database, seed=None, first_block=0):
+    def serializeDB(self, database, seed=None, first_block=0, matvec=None):
         """DiagonalEnroller::serializeDB (src/enroller/enroller_diag.cpp:12-53).  Normalises `database` IN PLACE like
         the reference; the ciphertexts go straight into HBM instead of serial/db_diagonal/index<t>.bin.  first_block > 0:
-        `database` is one shard (a contiguous range of 16384-vector blocks) of a larger database."""
+        `database` is one shard (a contiguous range of 16384-vector blocks) of a larger database.  matvec: None = the context's
+        policy (Context.set_matvec), or "hoisted" / "bsgs" (a sharded enrolment passes one decision to every shard)."""
         assert database.dtype == np.float64 and database.flags.c_contiguous
         assert database.shape == (self.numVectors, self.cc.dim)
-        _chk(self.cc.L.hydia_db_enroll_shard(self.cc.h, _p(database), self.numVectors, _p(_seed(seed)), first_block))
+        mv = 0 if matvec is None else Context.MATVEC[matvec]
+        _chk(self.cc.L.hydia_db_enroll_shard_ex(self.cc.h, _p(database), self.numVectors, _p(_seed(seed)), first_block, mv))
 
 
 class DiagonalReceiver:

@@ -39,6 +39,13 @@ def shard_vectors(n_total, slots, world, rank):
     return min(blo * slots, n_total), min(bhi * slots, n_total)
 
 
+def group_wants_bsgs(cc, n_total, world):
+    """ONE form of the mat-vec for a sharded database (include/hydia.h, hydia_set_matvec): the context's policy applied to the LARGEST
+    shard — every rank computes the same answer from (n_total, world) and its own (identically configured) context, no exchange."""
+    G = -(-n_total // cc.slots)
+    return cc.want_bsgs(max(hi - lo for lo, hi in (shard_blocks(G, world, r) for r in range(world))))
+
+
 # ------------------------------------------------------------------ one process, R contexts
 class ShardGroup:
     """R contexts of one process, one per entry of `devices` (a GPU may appear several times).  `ctx0` is where queries are
@@ -122,12 +129,14 @@ class DistDiagonalEnroller:
     def __init__(self, cc, n_total, rank, world):
         self.cc, self.n_total, self.rank, self.world = cc, n_total, rank, world
         self.first, self.last = shard_vectors(n_total, cc.slots, world, rank)
+        self.bsgs = group_wants_bsgs(cc, n_total, world)
 
     def serializeDB(self, rows, seed=None):
         n_local = self.last - self.first
         assert rows.shape == (n_local, self.cc.dim)
         if n_local:
-            _h.DiagonalEnroller(self.cc, n_local).serializeDB(rows, seed=seed, first_block=self.first // self.cc.slots)
+            _h.DiagonalEnroller(self.cc, n_local).serializeDB(rows, seed=seed, first_block=self.first // self.cc.slots,
+                                                              matvec="bsgs" if self.bsgs else "hoisted")
 
 
 class DistDiagonalSender:
@@ -155,9 +164,11 @@ class DistDiagonalSender:
         # Loop A: option A = every rank computes all 511 rotations itself; option B (rotation_split) = rank k of the K
         # ranks that hold blocks computes the contiguous range shard_blocks(dim, K, k) and the ranges are all-gathered (3 GiB in all
         # over xGMI), so the node does loop A's work once instead of once per GPU.  Same ciphertexts either way.
-        self.rotation_split = bool(rotation_split) and world > 1
         self.active = [r for r, (lo, hi) in enumerate(self.ranges) if hi > lo]
         K = len(self.active)
+        # the baby-step / giant-step form needs B - 1 rotations per query: nothing worth sharing out
+        self.bsgs = hasattr(cc, "want_bsgs") and group_wants_bsgs(cc, n_total, world)
+        self.rotation_split = bool(rotation_split) and world > 1 and K > 1 and not self.bsgs
         self.rot_ranges = {r: shard_blocks(cc.dim, K, k) for k, r in enumerate(self.active)}
         self.rot_even = K > 0 and cc.dim % K == 0 and K == world  # every rank holds blocks and the ranges are equal: in-place all_gather
 

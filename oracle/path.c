@@ -436,6 +436,113 @@ hy_ct **hyo_index_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q,
     }
     return score;
 }
+/* ------------------------------------------------------------------ baby-step / giant-step form of the same mat-vec
+ * BASELINE.json's north_star asks for "BSGS rotations of the diagonalized mat-vec"; the reference itself hoists all dim - 1
+ * rotations (sender_diag.cpp:22-26, SURVEY "fact 2", which allows the reorganisation when decrypted results stay within 1e-4).
+ * With i = b + B g (B babies, dim / B giants) and Rot_i = Rot_{Bg} o Rot_b:
+ *     sum_i Rot_i(q) . db_i  =  sum_g Rot_{Bg}( sum_b Rot_b(q) . Rot_{-Bg}(db_{b + Bg}) )
+ * The enroller rotates diagonal i by -B (i div B) slots IN THE CLEAR before encrypting it (same ciphertext order, same nonces), the
+ * sender needs B - 1 hoisted rotations of the query instead of dim - 1, relinearises the dim / B partial sums of a block and
+ * rotates them by B g (ordinary key switches with the rotation keys B, 2B, ...), adds, rescales.  Worth it while the blocks on a
+ * GPU are few (the per-block giant steps cost more than the per-query babies they replace beyond ~4 blocks). */
+int hyo_bsgs_babies(const hy_params *p) {
+    int B = 1;
+    while (B * B < p->dim) B <<= 1;
+    return B;
+}
+void hyo_enroll_layout_row_bsgs(const hy_params *p, const double *db, size_t n, size_t t, double *slots) {
+    size_t S = p->slots, i = t % p->dim, sh = (size_t)hyo_bsgs_babies(p) * (i / hyo_bsgs_babies(p));
+    double *plain = (double *)malloc(sizeof(double) * S);
+    hyo_enroll_layout_row(p, db, n, t, plain);
+    for (size_t s = 0; s < S; s++) slots[s] = plain[(s + S - sh % S) % S]; /* Rot_{-sh}: slot s takes slot s - sh */
+    free(plain);
+}
+hy_ct **hyo_enroll_bsgs(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts) {
+    size_t dim = p->dim;
+#pragma omp parallel for
+    for (size_t v = 0; v < n; v++) hyo_normalize(db + v * dim, (int)dim);
+    size_t T = hyo_enroll_num_cts(p, n);
+    hy_ct **out = (hy_ct **)calloc(T, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+    for (size_t t = 0; t < T; t++) {
+        double *slots = (double *)malloc(sizeof(double) * p->slots);
+        hyo_enroll_layout_row_bsgs(p, db, n, t, slots);
+        out[t] = hyo_encrypt(p, k, slots, p->slots, seed, DB_NONCE_BASE + t);
+        free(slots);
+    }
+    *n_cts = T;
+    return out;
+}
+hy_ct **hyo_compute_similarity_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out) {
+    const int dim = p->dim, N = p->N, B = hyo_bsgs_babies(p), NG = (dim + B - 1) / B;
+    size_t G = (n + p->slots - 1) / p->slots;
+    hy_ct **rot = (hy_ct **)calloc(B, sizeof(hy_ct *));
+    rot[0] = hyo_ct_clone(p, q);
+    u64 *dig = hyo_hoist_precompute(p, q->d + (size_t)q->nl * N, q->nl);
+#pragma omp parallel for schedule(dynamic)
+    for (int b = 1; b < B; b++) rot[b] = hyo_rotate_hoisted(p, q, dig, hyo_keys_rot(k, b), b);
+    free(dig);
+    hy_ct **sim = (hy_ct **)calloc(G, sizeof(hy_ct *));
+    for (size_t m = 0; m < G; m++) {
+        hy_ct **part = (hy_ct **)calloc(NG, sizeof(hy_ct *));
+#pragma omp parallel for schedule(dynamic)
+        for (int g = 0; g < NG; g++) {
+            hy_ct *acc = NULL;
+            for (int b = 0; b < B && g * B + b < dim; b++) {
+                hy_ct *t = hyo_mult_norelin(p, rot[b], db[m * dim + g * B + b]);
+                if (!acc) acc = t;
+                else {
+                    hyo_add_inplace(p, acc, t);
+                    hyo_ct_free(t);
+                }
+            }
+            hyo_relin_inplace(p, k, acc);
+            if (g > 0) {
+                hy_ct *r = hyo_rotate(p, k, acc, g * B);
+                hyo_ct_free(acc);
+                acc = r;
+            }
+            part[g] = acc;
+        }
+        for (int g = 1; g < NG; g++) {
+            hyo_add_inplace(p, part[0], part[g]);
+            hyo_ct_free(part[g]);
+        }
+        sim[m] = part[0];
+        free(part);
+        hyo_rescale_inplace(p, sim[m]);
+    }
+    hyo_ct_array_free(rot, B);
+    *n_out = G;
+    return sim;
+}
+hy_ct **hyo_index_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out) {
+    hy_ct **score = hyo_compute_similarity_bsgs(p, k, q, db, n, n_out);
+#pragma omp parallel for
+    for (size_t i = 0; i < *n_out; i++) {
+        hy_ct *c = hyo_chebyshev_compare(p, k, score[i], MATCH_THRESHOLD, COMP_DEPTH);
+        hyo_ct_free(score[i]);
+        score[i] = c;
+    }
+    return score;
+}
+hy_ct *hyo_membership_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n) {
+    size_t G;
+    hy_ct **score = hyo_index_scenario_bsgs(p, k, q, db, n, &G);
+    hy_ct *m = score[0];
+    for (size_t i = 1; i < G; i++) {
+        hyo_add_inplace(p, m, score[i]);
+        hyo_ct_free(score[i]);
+    }
+    free(score);
+    for (int r = 1; r < p->slots; r <<= 1) {
+        hy_ct *t = hyo_rotate(p, k, m, r);
+        hyo_add_inplace(p, m, t);
+        hyo_ct_free(t);
+    }
+    return m;
+}
+
 /* ---- the reference's on-disk hand-off between enroller and sender.  DiagonalEnroller::serializeDBThread writes one file per
  * ciphertext, "serial/db_diagonal/index<t>.bin" (enroller_diag.cpp:158-166), and computeSimilarityThread reads its file back
  * INSIDE the timed parallel loop of every query (sender_diag.cpp:85-94).  OpenFHE's cereal BINARY layout is undocumented in the

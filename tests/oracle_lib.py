@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB = None
 
+BSGS_MAX_BLOCKS = 4  # the product's auto rule (include/hydia.h hydia_bsgs_max_blocks): mirrored so that oracle and GPU pick the same form
+
 u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
 
@@ -91,6 +93,12 @@ def lib():
         "hyo_compute_similarity": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
         "hyo_index_scenario": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
         "hyo_membership_scenario": (vp, [vp, vp, vp, vp, C.c_size_t]),
+        "hyo_bsgs_babies": (C.c_int, [vp]),
+        "hyo_enroll_layout_row_bsgs": (None, [vp, vp, C.c_size_t, C.c_size_t, vp]),
+        "hyo_enroll_bsgs": (vp, [vp, vp, vp, C.c_size_t, vp, vp]),
+        "hyo_compute_similarity_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
+        "hyo_index_scenario_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
+        "hyo_membership_scenario_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t]),
         "hyo_db_write_files": (C.c_int, [vp, vp, C.c_size_t, C.c_char_p]),
         "hyo_index_scenario_files": (vp, [vp, vp, vp, C.c_char_p, C.c_size_t, vp]),
         "hyo_decrypt_membership": (C.c_int, [vp, vp, vp]),
@@ -383,12 +391,19 @@ class Oracle:
         return Ct(self.P, self.L.hyo_chebyshev_compare(self.P.h, self.K.h, ct.h, delta, depth))
 
     # ---- roles
-    def enroll(self, db, seed):
-        """DiagonalEnroller::serializeDB — normalises `db` in place (like the reference)."""
+    def enroll(self, db, seed, matvec=None):
+        """DiagonalEnroller::serializeDB — normalises `db` in place (like the reference).  matvec: "hoisted" (the reference's form),
+        "bsgs" (pre-rotated diagonals for the baby-step / giant-step mat-vec) or None = the product's auto rule: bsgs while the
+        database has at most BSGS_MAX_BLOCKS blocks.  The returned array remembers its form; the sender methods follow it."""
         assert db.dtype == np.float64 and db.flags.c_contiguous and db.shape[1] == self.P.dim
+        G = -(-db.shape[0] // self.P.slots)
+        bsgs = (G <= BSGS_MAX_BLOCKS) if matvec is None else {"hoisted": False, "bsgs": True}[matvec]
         n_out = C.c_size_t(0)
-        h = self.L.hyo_enroll(self.P.h, self.K.h, _ptr(db), db.shape[0], _ptr(seed_bytes(seed)), C.byref(n_out))
-        return CtArray(self.P, h, n_out.value)
+        fn = self.L.hyo_enroll_bsgs if bsgs else self.L.hyo_enroll
+        h = fn(self.P.h, self.K.h, _ptr(db), db.shape[0], _ptr(seed_bytes(seed)), C.byref(n_out))
+        arr = CtArray(self.P, h, n_out.value)
+        arr.bsgs = bsgs
+        return arr
 
     def encrypt_query(self, query, seed, nonce=1):
         query = np.ascontiguousarray(query, dtype=np.float64)
@@ -399,16 +414,19 @@ class Oracle:
 
     def compute_similarity(self, q, db, n):
         n_out = C.c_size_t(0)
-        h = self.L.hyo_compute_similarity(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
+        fn = self.L.hyo_compute_similarity_bsgs if getattr(db, "bsgs", False) else self.L.hyo_compute_similarity
+        h = fn(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
         return CtArray(self.P, h, n_out.value)
 
     def index_scenario(self, q, db, n):
         n_out = C.c_size_t(0)
-        h = self.L.hyo_index_scenario(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
+        fn = self.L.hyo_index_scenario_bsgs if getattr(db, "bsgs", False) else self.L.hyo_index_scenario
+        h = fn(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
         return CtArray(self.P, h, n_out.value)
 
     def membership_scenario(self, q, db, n):
-        return Ct(self.P, self.L.hyo_membership_scenario(self.P.h, self.K.h, q.h, db.h, n))
+        fn = self.L.hyo_membership_scenario_bsgs if getattr(db, "bsgs", False) else self.L.hyo_membership_scenario
+        return Ct(self.P, fn(self.P.h, self.K.h, q.h, db.h, n))
 
     def write_db_files(self, db, directory):
         """one index<t>.bin per ciphertext (enroller_diag.cpp:158-166)"""

@@ -79,9 +79,13 @@ def test_client_side_bit_exact_full_ring(im, full):
         assert np.array_equal(cc.db_export_ct(t), dbc[t].data()), t
 
 
-def test_three_block_sender_bit_exact_full_ring(im, full):
-    """(ii) n = 40000 -> G = 3 blocks on the default fast path (batched X = 3 tails, uneven lane split)."""
+@pytest.mark.parametrize("matvec", ["hoisted", "bsgs"])
+def test_three_block_sender_bit_exact_full_ring(im, full, matvec):
+    """(ii) n = 40000 -> G = 3 blocks on the default fast path (batched X = 3 tails, uneven lane split), in BOTH forms of the mat-vec:
+    the reference's 511 hoisted rotations (sender_diag.cpp:22-26) and the baby-step / giant-step form (31 babies, 16 giant steps per
+    block on pre-rotated diagonals) — each equal to the oracle's restatement of that form, bit for bit."""
     P, K, Or, cc = full
+    cc.set_matvec(matvec)
     n = 40000
     rng = np.random.default_rng(77)
     db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
@@ -91,8 +95,10 @@ def test_three_block_sender_bit_exact_full_ring(im, full):
     query = np.ones(512)
     cos = (db / np.linalg.norm(db, axis=1, keepdims=True)) @ (query / np.linalg.norm(query))
     a = db.copy()
-    dbc = Or.enroll(a, 8)
+    dbc = Or.enroll(a, 8, matvec=matvec)
     im.DiagonalEnroller(cc, n).serializeDB(db, seed=8)
+    cc.set_matvec("auto")
+    assert cc.db_kind() == (6 if matvec == "bsgs" else 5)
     q = Or.encrypt_query(query, 2, 9)
     receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
     gq = receiver.encryptQuery(query, seed=2, nonce=9)

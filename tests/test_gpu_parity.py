@@ -40,6 +40,8 @@ def load_db(cc, dbc, n):
     assert cc.db_num_cts(n) == len(dbc)
     for t in range(len(dbc)):
         cc.db_import_ct(t, dbc[t].data())
+    if getattr(dbc, "bsgs", False):  # the oracle enrolled in the baby-step / giant-step form
+        cc.db_set_kind(6)
 
 
 @pytest.fixture(scope="module")

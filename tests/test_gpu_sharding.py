@@ -30,8 +30,11 @@ def make_db(n, dim, planted, seed):
     return db
 
 
-def single_context_results(im, prm, n, db, planted, query, kseed=31, dseed=8, qseed=2):
+def single_context_results(im, prm, n, db, planted, query, kseed=31, dseed=8, qseed=2, matvec="hoisted"):
+    """matvec: the form of the mat-vec, fixed explicitly — "auto" would pick by the blocks a context holds, and a shard holds fewer
+    than the single context it is compared with (results are bit-identical between runs of the SAME form)"""
     cc = im.Context(prm, 0)
+    cc.set_matvec(matvec)
     cc.keygen(kseed)
     a = db.copy()
     im.DiagonalEnroller(cc, n).serializeDB(a, seed=dseed)
@@ -49,8 +52,9 @@ def single_context_results(im, prm, n, db, planted, query, kseed=31, dseed=8, qs
     return out
 
 
-def check_group(im, prm, devices, n, db, planted, query, want, splits=(True, False)):
+def check_group(im, prm, devices, n, db, planted, query, want, splits=(True, False), matvec="hoisted"):
     grp = im.ShardGroup(devices, prm)
+    grp.ctx0.set_matvec(matvec)  # the group enrols every shard in shard 0's form
     grp.keygen(31)
     b = db.copy()
     im.ShardedDiagonalEnroller(grp, n).serializeDB(b, seed=8)
@@ -90,9 +94,10 @@ def test_shard_group_bit_identical_small_ring(im, n, planted):
     prm = im.default_params(log_n=11, vector_dim=64)
     db = make_db(n, 64, planted, n)
     query = np.ones(64)
-    want = single_context_results(im, prm, n, db, planted, query)
-    for R in (2, 3, 5):
-        check_group(im, prm, [0] * R, n, db, planted, query, want)
+    for matvec in ("hoisted", "bsgs"):  # both forms of the mat-vec: shards and single context agree bit for bit within a form
+        want = single_context_results(im, prm, n, db, planted, query, matvec=matvec)
+        for R in (2, 3, 5):
+            check_group(im, prm, [0] * R, n, db, planted, query, want, matvec=matvec, splits=(True, False) if matvec == "hoisted" else (True,))
 
 
 @pytest.mark.parametrize("R", [2, 4, 8])
@@ -126,6 +131,7 @@ rank, world, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys
 dist.init_process_group("gloo")
 prm = im.default_params(log_n=11, vector_dim=64)
 cc = im.Context(prm, 0)
+cc.set_matvec("hoisted")
 cc.keygen(31)
 planted = [0, 1024, n - 1]
 db = make_db(n, 64, planted, n)
@@ -262,11 +268,11 @@ class ThreadDist:
         self.bar.wait()
 
 
-n, world, split = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "1"
+n, world, split, matvec = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "1", sys.argv[5]
 prm = im.default_params(log_n=11, vector_dim=64)
 planted = sorted({0, min(1024, n - 1), n - 1})
 db = make_db(n, 64, planted, n)
-want = single_context_results(im, prm, n, db, planted, np.ones(64))
+want = single_context_results(im, prm, n, db, planted, np.ones(64), matvec=matvec)
 td = ThreadDist(world)
 got, errors = {}, []
 
@@ -276,6 +282,7 @@ def rank_main(rank):
         td.bind(rank)
         with torch.cuda.stream(torch.cuda.Stream()):     # every rank has its own "current" stream, like separate processes
             cc = im.Context(prm, 0)
+            cc.set_matvec(matvec)
             cc.keygen(31)
             enr = im.DistDiagonalEnroller(cc, n, rank, world)
             enr.serializeDB(np.ascontiguousarray(db[enr.first:enr.last]), seed=8)
@@ -309,8 +316,9 @@ print("thread-dist ok")
 '''
 
 
-@pytest.mark.parametrize("n,world,split", [(5000, 3, True), (1000, 3, True), (5000, 2, True), (5000, 3, False)])
-def test_dist_sender_device_staging_under_async_collectives(tmp_path, n, world, split):
+@pytest.mark.parametrize("n,world,split,matvec", [(5000, 3, True, "hoisted"), (1000, 3, True, "hoisted"), (5000, 2, True, "hoisted"),
+                                                  (5000, 3, False, "hoisted"), (5000, 3, True, "bsgs")])
+def test_dist_sender_device_staging_under_async_collectives(tmp_path, n, world, split, matvec):
     """DistDiagonalSender with staging="device" and world = 3 (n = 5000: uneven shards of 2 + 2 + 1 blocks of 1024 vectors; n = 1000: one
     block, ranks 1 and 2 own nothing): three threads, three
     contexts on GPU 0, collectives with NCCL's asynchronous stream semantics (ThreadDist in the script above: RCCL itself refuses two
@@ -321,7 +329,7 @@ def test_dist_sender_device_staging_under_async_collectives(tmp_path, n, world, 
     next to the library's, started before anything forks)."""
     script = tmp_path / "thread_dist.py"
     script.write_text(THREAD_DIST_SCRIPT)
-    r = subprocess.run([sys.executable, str(script), ROOT, str(n), str(world), "1" if split else "0"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(n), str(world), "1" if split else "0", matvec], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "thread-dist ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
@@ -330,6 +338,7 @@ def test_rotation_ranges_reassemble_loop_a(im):
     and the *_rotated scenarios on them the ciphertexts of the plain scenarios — what the rotation-split multi-GPU sender relies on."""
     n = 20000
     cc = im.Context()
+    cc.set_matvec("hoisted")  # the form whose loop A is worth sharing out (two blocks would otherwise pick baby-step / giant-step)
     cc.keygen(31)
     db = make_db(n, 512, [7, n - 1], 3)
     im.DiagonalEnroller(cc, n).serializeDB(db, seed=8)

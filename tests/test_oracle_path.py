@@ -52,14 +52,16 @@ def test_normalize_matches_reference_semantics(small_params):
     assert not z.any()
 
 
+@pytest.mark.parametrize("matvec", ["hoisted", "bsgs"])
 @pytest.mark.parametrize("n,matches", [(1500, [0, 700, 1499]), (64, [63]), (1, [0]), (1024, []), (1025, [1024])])
-def test_hydia_path_small_ring(small_params, small_keys, n, matches):
+def test_hydia_path_small_ring(small_params, small_keys, n, matches, matvec):
+    """both forms of the mat-vec: the reference's hoisted rotations and the baby-step / giant-step restatement (pre-rotated diagonals)"""
     P, Or = small_params, O.Oracle(small_params, small_keys)
     rng = np.random.default_rng(n)
     db = synth_db(rng, n, P.dim, matches)
     query = np.ones(P.dim)
     cos = cosine(db, query)
-    dbc = Or.enroll(db.copy(), 99)
+    dbc = Or.enroll(db.copy(), 99, matvec=matvec)
     assert len(dbc) == P.L.hyo_enroll_num_cts(P.h, n)
     q = Or.encrypt_query(query, 5, 1)
     sim = Or.compute_similarity(q, dbc, n)
@@ -73,6 +75,23 @@ def test_hydia_path_small_ring(small_params, small_keys, n, matches):
     assert Or.decrypt_index(idx) == sorted(matches)
     mem = Or.membership_scenario(q, dbc, n)
     assert Or.decrypt_membership(mem) == (len(matches) > 0)
+
+
+def test_bsgs_layout_is_the_hoisted_layout_rotated_in_the_clear(small_params):
+    """slot vector of ciphertext t in the baby-step / giant-step form = the reference layout's (enroller_diag.cpp:99-156) rotated by
+    -B (i div B) slots, B = hyo_bsgs_babies (8 at vector_dim 64, 32 at 512): what Rot_{Bg} undoes after the inner sums"""
+    P = small_params
+    B = P.L.hyo_bsgs_babies(P.h)
+    assert B == 8 and O.Params(log_n=12, depth=3, dim=512).L.hyo_bsgs_babies(O.Params(log_n=12, depth=3, dim=512).h) == 32
+    rng = np.random.default_rng(2)
+    n = 1500
+    db = rng.standard_normal((n, P.dim))
+    plain, rot = np.zeros(P.slots), np.zeros(P.slots)
+    for t in (0, 7, 8, 9, 63, 64 + 17, 64 + 63):
+        P.L.hyo_enroll_layout_row(P.h, db.ctypes.data, n, t, plain.ctypes.data)
+        P.L.hyo_enroll_layout_row_bsgs(P.h, db.ctypes.data, n, t, rot.ctypes.data)
+        sh = B * ((t % P.dim) // B)
+        assert np.array_equal(rot, np.roll(plain, sh)), t  # slot s takes slot s - sh
 
 
 def test_zero_vector_row_and_enroll_normalises_in_place(small_params, small_keys):
@@ -214,7 +233,7 @@ def test_file_handoff_variant_equals_in_memory_path(small_params, small_keys, tm
     rng = np.random.default_rng(3)
     n = 2100
     db = synth_db(rng, n, P.dim, [7, 2000])
-    dbc = Or.enroll(db, 9)
+    dbc = Or.enroll(db, 9, matvec="hoisted")  # the reference's own form: its files feed its hoisted sender
     Or.write_db_files(dbc, tmp_path)
     assert len(list(tmp_path.iterdir())) == len(dbc)
     q = Or.encrypt_query(np.ones(P.dim), 5, 1)

@@ -125,8 +125,8 @@ def _worker(rank, world, port, G, split, out):
     lo, hi = sharding.shard_blocks(G, world, rank)
     sender = sharding.DistDiagonalSender(cc, n_total, dist, rank, world, staging="host",
                                          make_sender=lambda c, n: FakeSender(lo, hi, query), rotation_split=split)
-    assert sender.rotation_split == split
-    if split:  # the ranks that hold blocks share the rotations 0 .. dim-1 between them, in rank order
+    assert sender.rotation_split == (split and len(sender.active) > 1)  # one rank with blocks: nothing to share out
+    if sender.rotation_split:  # the ranks that hold blocks share the rotations 0 .. dim-1 between them, in rank order
         ranges = [sender.rot_ranges[r] for r in sender.active]
         assert ranges[0][0] == 0 and ranges[-1][1] == cc.dim and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     assert (sender.lo, sender.hi) == (lo, hi) and (sender.local is None) == (hi == lo)
@@ -150,10 +150,11 @@ def _worker(rank, world, port, G, split, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,G,split", [(2, 5, False), (2, 1, True), (3, 8, True), (2, 4, True)])
+@pytest.mark.parametrize("world,G,split", [(2, 5, False), (2, 1, True), (3, 8, True), (2, 4, True), (3, 2, True)])
 def test_dist_sender_host_logic(world, G, split):
     """split = loop A's rotations shared out over the ranks that hold blocks and all-gathered (SURVEY 8e option B); (2, 1): one of the
-    two ranks holds no block and joins the collectives with an empty range"""
+    two ranks holds no block — a single rank with blocks computes every rotation itself; (3, 2): the third rank holds no block and joins
+    the all-gather with an empty range"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
