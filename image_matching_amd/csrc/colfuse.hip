@@ -21,6 +21,9 @@ namespace {
 // k_moddown_rescale_conv + k_ntt15_p1<false>: bit-identical (HYDIA_NO_COLFUSE runs those instead).
 // LDS: two 32 KiB exchange images used alternately (ONE barrier per tile transform), the sources' phase-B twiddles, two alternating
 // sets for the targets.  256 registers per lane -> two workgroups per CU; every global load of a workgroup is issued up front.
+// Merged ModDown + Rescale (MDR) carries a fifth value per row, the dropped limb's centred residue: it lives in the second image's
+// LDS (one slot per lane and row) instead of 32 more registers — 160 + working registers spilled to scratch (1.43 against 2.1 TB/s) —
+// and that variant exchanges through ONE image with a second barrier per transform.
 constexpr int CF_LDS_BYTES = 2 * 128 * 32 * 8 + (HY_CF_SRC + 1 + 2) * 128 * 16;
 
 // y: in = raw pass-2' values of rows 8h + l (h = g + 8 hh) at index 8 hh + l; out = canonical coefficient-form residues (times sc) of
@@ -69,13 +72,54 @@ DEV void cf_inverse(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = ar.fin_inv(v[k], sc, scs);
 }
-DEV void cf_inverse_any(const NttTables &T, int m, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs, u64 (&y)[16]) {
+// Conversion sums sum_s y_s f_s (four terms, y_s < 2^60, f_s < 2^60).  A 128-bit multiply-accumulate costs ~12 instructions as the
+// compiler builds it (four partial products, each followed by carry handling).  With both operands cut at 30 bits —
+// y = yh 2^30 + yl, f = fh 2^30 + fl — the three partial sums  sum yl fl,  sum (yl fh + yh fl),  sum yh fh  stay below 2^63, so they
+// are plain chains of v_mad_u64_u32 with no carries (16 for four terms), combined once: 28 instructions instead of 50.
+// Sources are kept in that split form (yl in the low dword, yh in the high one: the same two registers).
+DEV u64 cf_split30(u64 v) { return (v & 0x3FFFFFFFull) | ((v >> 30) << 32); }
+struct CfConst {
+    unsigned lo[HY_CF_SRC], hi[HY_CF_SRC];
+    u64 full[HY_CF_SRC];
+    DEV void set(int s, u64 f) {
+        lo[s] = (unsigned)f & 0x3FFFFFFFu;
+        hi[s] = (unsigned)(f >> 30);
+        full[s] = f;
+    }
+};
+// The many-target kernel keeps 128 source registers alive across its target loop; the three partial sums per row of the split form
+// push it past its 256 registers (300-400 bytes of spills per lane, measured), so it stays with the plain 128-bit multiply-accumulate
+// on unsplit residues; the one-target kernel, which has registers to spare, takes the split form.
+DEV u128 cf_mac4_plain(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
+    return (u128)y0 * f.full[0] + (u128)y1 * f.full[1] + (u128)y2 * f.full[2] + (u128)y3 * f.full[3];
+}
+DEV u128 cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
+    const u64 y[HY_CF_SRC] = {y0, y1, y2, y3};
+    u64 pll = 0, pmid = 0, phh = 0;
+#pragma unroll
+    for (int s = 0; s < HY_CF_SRC; s++) {
+        const unsigned yl = (unsigned)y[s], yh = (unsigned)(y[s] >> 32);
+        pll += (u64)yl * f.lo[s];
+        pmid += (u64)yl * f.hi[s];
+        pmid += (u64)yh * f.lo[s];
+        phh += (u64)yh * f.hi[s];
+    }
+    return (u128)pll + ((u128)pmid << 30) + ((u128)phh << 60);
+}
+
+// split: leave the residues in the 30 + 30 bit form the conversion sums take (conversion sources; not the dropped limb)
+DEV void cf_inverse_any(const NttTables &T, int m, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs, u64 (&y)[16],
+                        bool split) {
     const ModC M = T.mod[m];
     const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
     const ulonglong2 *__restrict__ tw = (fp ? T.itwf : T.itwp) + (size_t)m * 32768;
     if (fp) cf_inverse<FpA>(FpA(M), tw, ltw, lds, g, col, sc, scs, y);
     else if ((T.pm_mask >> m) & 1u) cf_inverse<IntP>(IntP(M), tw, ltw, lds, g, col, sc, scs, y);
     else cf_inverse<IntA>(IntA(M), tw, ltw, lds, g, col, sc, scs, y);
+    if (split) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) y[k] = cf_split30(y[k]);
+    }
 }
 // v: operands of rows g + 8k (this arithmetic's representation of canonical residues); the raw pass-1 image leaves through d
 template <class A>
@@ -117,16 +161,14 @@ DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 // Integer targets (the 60-bit limb 0): canonical residue, single-word Barrett on the top bits (reduce128k: at most four products of
 // residues below 2^60 with constants below q).
 template <class A, bool MDR>
-DEV void cf_convert(const A ar, const ModC &M, const u64 (&f)[HY_CF_SRC], const u64 (&y)[HY_CF_SRC][16], const u64 (&um)[16], unsigned neg,
-                    typename A::T (&v)[16]) {
+DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
+                    unsigned neg, typename A::T (&v)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u128 a = 0;
-#pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) a += (u128)y[s][k] * f[s];
+        const u128 a = cf_mac4_plain(y[0][k], y[1][k], y[2][k], y[3][k], f);
         u64 r = reduce128k(a, M);
         if (MDR) {
-            const u64 c = reduce64(um[k], M);
+            const u64 c = reduce64(um[k * 256], M);
             r = addmod(r, ((neg >> k) & 1u) ? negmod(c, M.q) : c, M.q);
         }
         v[k] = ar.from_canon(r);
@@ -138,21 +180,19 @@ DEV void cf_convert(const A ar, const ModC &M, const u64 (&f)[HY_CF_SRC], const 
 // instead of reduce128k + conversion (~32); |operand| <= 1.05 q (1.6 q with the dropped limb's centred residue).  The canonical
 // results after pass 2 are the same residues.
 template <bool MDR>
-DEV void cf_convert(const FpA ar, const ModC &M, const u64 (&f)[HY_CF_SRC], const u64 (&y)[HY_CF_SRC][16], const u64 (&um)[16], unsigned neg,
-                    double (&v)[16]) {
+DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
+                    unsigned neg, double (&v)[16]) {
     const double c64 = FpA::u2d(0ull - M.r64 * M.q);  // 2^64 mod q
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u128 a = 0;
-#pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) a += (u128)y[s][k] * f[s];
+        const u128 a = cf_mac4_plain(y[0][k], y[1][k], y[2][k], y[3][k], f);
         const u64 a0 = (u64)a;
         const double t1 = ar.mulmod2(FpA::u2d((u64)(a >> 64)), c64);
         const double h = (double)(unsigned)(a0 >> 32) * 4294967296.0;  // exact
         const double t0 = __fma_rn(-rint(h * ar.qinv), ar.q, h);
         double r = t1 + t0 + (double)(unsigned)a0;
         if (MDR) {
-            const double c = FpA::u2d(um[k]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
+            const double c = FpA::u2d(um[k * 256]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
             r += ((neg >> k) & 1u) ? -c : c;
         }
         v[k] = r;
@@ -162,7 +202,7 @@ DEV void cf_convert(const FpA ar, const ModC &M, const u64 (&f)[HY_CF_SRC], cons
 // grid (8 column tiles, XP polynomials, ncf maps x target slices), 256 threads: col = t & 31, g = t >> 5
 template <bool MDR>
 __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
-                                                           size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz, int pre) {
+                                                           size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz) {
     constexpr int N = 32768;
     extern __shared__ __attribute__((aligned(16))) u64 cf_smem[];
     u64 *const img = cf_smem;  // two exchange images of 128 x 32
@@ -175,40 +215,33 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
     const int t = threadIdx.x, col = t & 31, g = t >> 5;
     const int xp = blockIdx.y, c0 = blockIdx.x * 32;
     const u64 *sb = src + (size_t)xp * so + c0 + col;
-    // ---- every global load of the workgroup, up front.  pre: the sources are already canonical coefficient-form residues (their
-    // inverse transform ran as its own, wider launch: a launch too small to fill the chip keeps its serial chain short that way) —
-    // a lane then loads the rows g + 8k it converts, not the rows 8h + l pass 1' starts from
+    // ---- every global load of the workgroup, up front: the raw pass-2' values of rows 8h + l (h = g + 8 hh), where pass 1' starts
+    u64 *const umem = cf_smem + 4096 + t;  // MDR: lane t's slot of row k at umem[k * 256] (the second image)
     u64 y[HY_CF_SRC][16], um[16];
+    if (MDR) {
+        const u64 *sp = sb + (size_t)cf.urow * N;
 #pragma unroll
-    for (int s = 0; s < HY_CF_SRC; s++)
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) um[8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+    }
+    // (MDR: the last two sources are requested once the dropped limb has left its registers — their latency hides behind the first
+    // two sources' transforms, and the peak stays inside the 256 registers)
+    auto load_source = [&](int s) {
         if (s >= cf.nk) {
 #pragma unroll
             for (int k = 0; k < 16; k++) y[s][k] = 0;
         } else {
             const u64 *sp = sb + (size_t)cf.srow[s] * N;
-            if (pre) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) y[s][k] = sp[(size_t)(g + 8 * k) * 256];
-            } else {
-#pragma unroll
-                for (int hh = 0; hh < 2; hh++)
-#pragma unroll
-                    for (int l = 0; l < 8; l++) y[s][8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
-            }
-        }
-    if (MDR) {
-        const u64 *sp = sb + (size_t)cf.urow * N;
-        if (pre) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) um[k] = sp[(size_t)(g + 8 * k) * 256];
-        } else {
 #pragma unroll
             for (int hh = 0; hh < 2; hh++)
 #pragma unroll
-                for (int l = 0; l < 8; l++) um[8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
+                for (int l = 0; l < 8; l++) y[s][8 * hh + l] = sp[(size_t)(8 * (g + 8 * hh) + l) * 256];
         }
-    }
-    if (!pre && t < 128) {
+    };
+#pragma unroll
+    for (int s = 0; s < (MDR ? 2 : HY_CF_SRC); s++) load_source(s);
+    if (t < 128) {
 #pragma unroll
         for (int s = 0; s < HY_CF_SRC; s++)
             if (s < cf.nk) {
@@ -224,32 +257,37 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
     }
     __syncthreads();
     int buf = 0;
-    // ---- pass 1' of every source: raw -> canonical coefficient-form residues, in place in y / um
-    if (!pre) {
-    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, img + (buf ^= 1) * 4096, g, col, cf.ssc[0], cf.ssc_sh[0], y[0]);
-    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, img + (buf ^= 1) * 4096, g, col, cf.ssc[1], cf.ssc_sh[1], y[1]);
-    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, img + (buf ^= 1) * 4096, g, col, cf.ssc[2], cf.ssc_sh[2], y[2]);
-    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, img + (buf ^= 1) * 4096, g, col, cf.ssc[3], cf.ssc_sh[3], y[3]);
-    if (MDR) cf_inverse_any(T, cf.umod, sltw + HY_CF_SRC * 128, img + (buf ^= 1) * 4096, g, col, cf.usc, cf.usc_sh, um);
+    // MDR exchanges through image 0 only (image 1 holds the dropped limb's residues): a barrier before an image is rewritten
+#define CF_NEXT_IMAGE() (MDR ? (__syncthreads(), img) : img + (buf ^= 1) * 4096)
+    // ---- pass 1' of every source: raw -> canonical coefficient-form residues, in place in y / um (the dropped limb first: its
+    // registers are free again before the others are transformed)
+    if (MDR) {
+        cf_inverse_any(T, cf.umod, sltw + HY_CF_SRC * 128, CF_NEXT_IMAGE(), g, col, cf.usc, cf.usc_sh, um, false);
+#pragma unroll
+        for (int k = 0; k < 16; k++) umem[k * 256] = um[k];
+#pragma unroll
+        for (int s = 2; s < HY_CF_SRC; s++) load_source(s);
     }
+    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, CF_NEXT_IMAGE(), g, col, cf.ssc[0], cf.ssc_sh[0], y[0], false);
+    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, CF_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], false);
+    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, CF_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], false);
+    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, CF_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], false);
     // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
     unsigned neg = 0;
     if (MDR) {
         const ModC Ml = T.mod[cf.l];
         const u64 half = Ml.q >> 1;
-        u64 fl[HY_CF_SRC];
+        CfConst fl;
 #pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) fl[s] = s < cf.nk ? cf.fl[s] : 0;
+        for (int s = 0; s < HY_CF_SRC; s++) fl.set(s, s < cf.nk ? cf.fl[s] : 0);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            u128 a = 0;
-#pragma unroll
-            for (int s = 0; s < HY_CF_SRC; s++) a += (u128)y[s][k] * fl[s];
-            const u64 yl = submod(um[k], reduce128k(a, Ml), Ml.q);
+            const u128 a = cf_mac4_plain(y[0][k], y[1][k], y[2][k], y[3][k], fl);
+            const u64 yl = submod(umem[k * 256], reduce128k(a, Ml), Ml.q);  // own slot: no barrier needed
             const bool ng = yl > half;
-            um[k] = ng ? Ml.q - yl : yl;
+            umem[k * 256] = ng ? Ml.q - yl : yl;
             neg |= (ng ? 1u : 0u) << k;
-        }
+            }
     }
     // ---- every target of this slice: conversion, pass 1, raw image out
     for (int tt = t_lo; tt < t_hi; tt++) {
@@ -260,24 +298,24 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         ulonglong2 *ltw = tltw + (tt & 1) * 128;
         if (t < 128) ltw[t] = tw[t];
         u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;  // cf_forward adds the lane's column
-        u64 *lds = img + (buf ^= 1) * 4096;
-        u64 f[HY_CF_SRC];
+        u64 *lds = CF_NEXT_IMAGE();
+        CfConst f;
 #pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) f[s] = s < cf.nk ? cf.f[s][tt] : 0;
+        for (int s = 0; s < HY_CF_SRC; s++) f.set(s, s < cf.nk ? cf.f[s][tt] : 0);
         if (fp) {
             const FpA ar(M);
             double v[16];
-            cf_convert<MDR>(ar, M, f, y, um, neg, v);
+            cf_convert<MDR>(ar, M, f, y, umem, neg, v);
             cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
         } else if ((T.pm_mask >> m) & 1u) {
             const IntP ar(M);
             u64 v[16];
-            cf_convert<IntP, MDR>(ar, M, f, y, um, neg, v);
+            cf_convert<IntP, MDR>(ar, M, f, y, umem, neg, v);
             cf_forward<IntP>(ar, tw, ltw, lds, g, col, v, d);
         } else {
             const IntA ar(M);
             u64 v[16];
-            cf_convert<IntA, MDR>(ar, M, f, y, um, neg, v);
+            cf_convert<IntA, MDR>(ar, M, f, y, umem, neg, v);
             cf_forward<IntA>(ar, tw, ltw, lds, g, col, v, d);
         }
     }
@@ -304,13 +342,13 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
     const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
     const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
     if (t < 128) ltw[t] = tw[t];
-    u64 f[HY_CF_SRC], fl[HY_CF_SRC];
+    CfConst f, fl;
     const u64 *sp[HY_CF_SRC];
 #pragma unroll
     for (int s = 0; s < HY_CF_SRC; s++) {
         const bool on = s < cf.nk;
-        f[s] = on ? cf.f[s][tt] : 0;
-        fl[s] = (MDR && on) ? cf.fl[s] : 0;
+        f.set(s, on ? cf.f[s][tt] : 0);
+        fl.set(s, (MDR && on) ? cf.fl[s] : 0);
         sp[s] = sb + (size_t)cf.srow[on ? s : 0] * N;  // absent sources re-read source 0 against a zero constant
     }
     const u64 *su = MDR ? sb + (size_t)cf.urow * N : sb;
@@ -320,18 +358,12 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
     // limb's centred residue (MDR) is formed from the same operands
     auto convert_row = [&](int k, u128 &a, u64 &mag, bool &ng) {
         const size_t off = (size_t)(g + 8 * k) * 256;
-        u128 al = 0;
-        a = 0;
-#pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) {
-            const u64 ys = sp[s][off];
-            a += (u128)ys * f[s];
-            if (MDR) al += (u128)ys * fl[s];
-        }
+        const u64 y0 = cf_split30(sp[0][off]), y1 = cf_split30(sp[1][off]), y2 = cf_split30(sp[2][off]), y3 = cf_split30(sp[3][off]);
+        a = cf_mac4(y0, y1, y2, y3, f);
         mag = 0;
         ng = false;
         if (MDR) {
-            const u64 yl = submod(su[off], reduce128k(al, Ml), Ml.q);
+            const u64 yl = submod(su[off], reduce128k(cf_mac4(y0, y1, y2, y3, fl), Ml), Ml.q);
             ng = yl > (Ml.q >> 1);
             mag = ng ? Ml.q - yl : yl;
         }
@@ -413,9 +445,9 @@ void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so
     const int tz = (nt_max + slices - 1) / slices;
     slices = (nt_max + tz - 1) / tz;
     if (mdr)
-        hipLaunchKernelGGL((k_ntt15_colfuse<true>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz, pre ? 1 : 0);
+        hipLaunchKernelGGL((k_ntt15_colfuse<true>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz);
     else
-        hipLaunchKernelGGL((k_ntt15_colfuse<false>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz, pre ? 1 : 0);
+        hipLaunchKernelGGL((k_ntt15_colfuse<false>), dim3(8, XP, ncf * slices), dim3(256), CF_LDS_BYTES, st, T, src, so, dst, dso, d_cf, slices, tz);
 }
 
 }  // namespace hk
