@@ -366,7 +366,7 @@ def main():
         bsgs = cc.db_kind() == 6
         # loop B's operands: the database once, the rotated queries once, the degree-2 accumulators once.  Hoisted form: dim rotated
         # queries, one accumulator per block; baby-step / giant-step form: B = 32 babies, dim / B accumulators per block
-        n_rot = cc.bsgs_babies() if bsgs else dim
+        n_rot = cc.db_babies() if bsgs else dim
         n_acc = G_local * (dim // n_rot if bsgs else 1)
         algo_bytes = (G_local * dim + n_rot) * 2 * nl * N * 8 + n_acc * 3 * nl * N * 8
         avg_launch_s = ms_tensor / max(launches, 1) / 1e3
@@ -405,8 +405,8 @@ def main():
                        "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
                        "matvec": ("baby-step / giant-step: %d hoisted rotations of the query, %d relinearised partial sums per block rotated by "
-                                  "multiples of %d (pre-rotated diagonals; chosen because this GPU holds <= %d blocks)"
-                                  % (n_rot - 1, dim // n_rot, n_rot, im.bsgs_max_blocks())) if bsgs else
+                                  "multiples of %d (pre-rotated diagonals; the split the auto rule picks for the %d blocks on this GPU)"
+                                  % (n_rot - 1, dim // n_rot, n_rot, G_local)) if bsgs else
                                  "hoisted: %d hoisted rotations of the query, one relinearisation per block (the reference's form)" % (dim - 1),
                        "sharding": "row-blocks per GPU (image_matching_amd.sharding.DistDiagonalSender): query broadcast, loop A %s, "
                                    "independent mat-vec per rank, RCCL gather of result ciphertexts in global block order"

@@ -12,7 +12,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .hydia import (Context, Ciphertext, DiagonalEnroller, DiagonalReceiver, DiagonalSender, HydiaError,  # noqa: F401
                     HersEnroller, HersReceiver, HersSender,
-                    byte_ledger, default_params, describe_params, compute_required_depth, bsgs_max_blocks, lib_path, load_library)
+                    byte_ledger, default_params, describe_params, compute_required_depth, lib_path, load_library)
 from .sharding import (ShardGroup, ShardedDiagonalEnroller, ShardedDiagonalSender, DistDiagonalEnroller,  # noqa: F401
                        DistDiagonalSender, shard_blocks, shard_vectors)
 

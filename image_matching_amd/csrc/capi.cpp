@@ -408,6 +408,7 @@ int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors) {
     REQUIRE(ctx && n_vectors >= 1, "bad argument");
     ctx->cx.db_resize(n_vectors, hydia_db_num_cts(ctx, n_vectors));
     ctx->cx.db_kind = 5;
+    ctx->cx.db_babies = ctx->cx.prm.dim;
     return HYDIA_OK;
     API_END
 }
@@ -425,7 +426,10 @@ int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data) {
     cx.db_store(t, tmp, 1);
     cx.sync();
     cx.pool.put(tmp);
-    if (cx.db_kind == 0) cx.db_kind = 5;
+    if (cx.db_kind == 0) {
+        cx.db_kind = 5;
+        cx.db_babies = cx.prm.dim;
+    }
     return HYDIA_OK;
     API_END
 }
@@ -461,23 +465,25 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     }
     cx.sync();
     cx.pool.put(tmp);
-    cx.db_kind = cx.want_bsgs((n_vectors + (size_t)cx.slots - 1) / (size_t)cx.slots) ? 6 : 5;  // random residues: either form's cost model
+    cx.db_babies = cx.babies_for((n_vectors + (size_t)cx.slots - 1) / (size_t)cx.slots);  // random residues: the cost model of the split auto picks
+    cx.db_kind = cx.db_babies < cx.prm.dim ? 6 : 5;
     return HYDIA_OK;
     API_END
 }
-// matvec: 0 = the context's own policy (hydia_set_matvec; auto by the blocks THIS context holds), 1 hoisted, 2 bsgs — a sharded
-// enrolment passes the group-wide decision so that every shard of one database uses the same form
+// matvec: 0 = the context's own policy (hydia_set_matvec; auto looks at the blocks THIS context holds), 1 hoisted, otherwise the baby
+// count — a sharded enrolment passes the group-wide decision so that every shard of one database uses the same split
 int hydia_db_enroll_shard_ex(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block, int matvec) {
     API_BEGIN
     use_device(ctx);
-    REQUIRE(ctx && db && seed && n >= 1 && matvec >= 0 && matvec <= 2, "bad argument");
+    REQUIRE(ctx && db && seed && n >= 1 && matvec >= 0, "bad argument");
     Context &cx = ctx->cx;
     const size_t G = (n + (size_t)cx.slots - 1) / (size_t)cx.slots;
-    const bool bsgs = matvec == 2 || (matvec == 0 && cx.want_bsgs(G));
+    const int B = cx.babies_for(G, matvec);
     cx.db_kind = 0;
     cx.db_resize(n, hydia_db_num_cts(ctx, n));
-    client_enroll(cx, db, n, seed, first_block, bsgs);
-    cx.db_kind = bsgs ? 6 : 5;
+    client_enroll(cx, db, n, seed, first_block, B);
+    cx.db_kind = B < cx.prm.dim ? 6 : 5;
+    cx.db_babies = B;
     return HYDIA_OK;
     API_END
 }
@@ -486,20 +492,29 @@ int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t se
     return hydia_db_enroll_shard_ex(ctx, db, n, seed, first_block, 0);
 }
 int hydia_set_matvec(hydia_ctx *ctx, int mode) {
-    REQUIRE(ctx && mode >= 0 && mode <= 2, "mat-vec mode is 0 (auto), 1 (hoisted) or 2 (bsgs)");
+    API_BEGIN
+    REQUIRE(ctx && mode >= 0, "mat-vec mode is 0 (auto), 1 (hoisted) or a baby count");
+    if (mode > 1) (void)ctx->cx.babies_for(1, mode);  // validates: a power of two dividing vector_dim
     ctx->cx.matvec_mode = mode;
     return HYDIA_OK;
+    API_END
 }
-/* which form the ciphertexts of an imported database are in (hydia_db_alloc + hydia_db_import_ct assume 5, the reference enroller's) */
-int hydia_db_set_kind(hydia_ctx *ctx, int kind) {
-    REQUIRE(ctx && (kind == 5 || kind == 6), "database kind is 5 (hoisted diagonals) or 6 (pre-rotated diagonals)");
-    if (!ctx->cx.d_db || ctx->cx.db_cts == 0 || ctx->cx.db_kind == 4) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
-    ctx->cx.db_kind = kind;
+/* form of an IMPORTED database: babies == vector_dim (hoisted: what hydia_db_alloc + hydia_db_import_ct assume, the reference
+ * enroller's ciphertexts) or the baby count its diagonals were pre-rotated for */
+int hydia_db_set_babies(hydia_ctx *ctx, int babies) {
+    API_BEGIN
+    REQUIRE(ctx, "null argument");
+    Context &cx = ctx->cx;
+    if (!cx.d_db || cx.db_cts == 0 || cx.db_kind == 4) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
+    cx.db_babies = cx.babies_for(1, babies == cx.prm.dim ? 1 : babies);
+    cx.db_kind = cx.db_babies < cx.prm.dim ? 6 : 5;
     return HYDIA_OK;
+    API_END
 }
 int hydia_get_matvec(const hydia_ctx *ctx) { return ctx ? ctx->cx.matvec_mode : -1; }
 int hydia_db_kind(const hydia_ctx *ctx) { return ctx ? ctx->cx.db_kind : 0; }
-size_t hydia_bsgs_max_blocks(void) { return HY_BSGS_MAX_BLOCKS; }
+int hydia_db_babies(const hydia_ctx *ctx) { return ctx && (ctx->cx.db_kind == 5 || ctx->cx.db_kind == 6) ? ctx->cx.db_babies : 0; }
+int hydia_auto_babies(const hydia_ctx *ctx, size_t blocks) { return ctx ? ctx->cx.babies_for(blocks) : 0; }
 int hydia_hers_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32]) {
     API_BEGIN
     use_device(ctx);

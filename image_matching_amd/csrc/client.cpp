@@ -193,7 +193,7 @@ void client_decrypt(Context &cx, const Ct &ct, double *out) {
 #define HY_NONCE_LIMIT (1ull << 40)
 // DiagonalEnroller::serializeDB: normalise IN PLACE (enroller_diag.cpp:32-35), then per group of `slots` rows: pack the
 // generalised diagonals (:37-45) and encrypt the vector_dim slot vectors (:48-52) into the resident HBM layout.
-void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32], size_t first_block, bool bsgs) {
+void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32], size_t first_block, int babies) {
     const int dim = cx.prm.dim, Nh = cx.slots;
     for (long long v = 0; v < (long long)n; v++) normalize(db + (size_t)v * dim, dim);
     const ChaChaKey key = make_key(seed);
@@ -209,7 +209,7 @@ void client_enroll(Context &cx, double *db, size_t n, const uint8_t seed[32], si
         const size_t rows = n > first ? std::min((size_t)Nh, n - first) : 0;
         if (rows)
             HIP_CHECK(hipMemcpyAsync(d_rows, db + first * dim, sizeof(double) * rows * dim, hipMemcpyHostToDevice, cx.stream));
-        hc::diag_pack(cx.stream, d_rows, (long long)rows, dim, Nh, d_slots, bsgs ? cx.bsgs_babies() : 0);
+        hc::diag_pack(cx.stream, d_rows, (long long)rows, dim, Nh, d_slots, (babies > 0 && babies < dim) ? babies : 0);
         encrypt_device(cx, d_slots, dim, key, HY_DB_NONCE_BASE + (first_block + g) * dim, d_cts);
         cx.db_store(g * dim, d_cts, dim);
     }

@@ -371,7 +371,12 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
     fuse_loop_a = getenv("HYDIA_NO_FUSE_LOOPA") == nullptr;
     colfuse = getenv("HYDIA_NO_COLFUSE") == nullptr;
-    if (const char *e = getenv("HYDIA_MATVEC")) matvec_mode = e[0] == 'h' ? 1 : e[0] == 'b' ? 2 : 0;
+    if (const char *e = getenv("HYDIA_MATVEC")) {  // auto | hoisted | bsgs | <baby count>
+        if (e[0] == 'h') matvec_mode = 1;
+        else if (e[0] == 'b') matvec_mode = bsgs_babies();
+        else if (e[0] >= '1' && e[0] <= '9') matvec_mode = babies_for(1, atoi(e));
+        else matvec_mode = 0;
+    }
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
     for (int j = 1; j < nQ; j++)
@@ -533,7 +538,7 @@ void Context::db_resize(size_t n_vectors, size_t cts) {
 namespace {
 struct DbFileHeader {
     char magic[8];  // "HYDIADB1"
-    uint32_t logN, nQ, dim, packed, kind, reserved;
+    uint32_t logN, nQ, dim, packed, kind, babies;  // babies: kind 5 / 6 — hoisted rotations the diagonals are laid out for (0 in old files = dim)
     uint64_t n_vectors, n_cts, ct_bytes;
     uint64_t moduli[HY_MAX_MODS];
 };
@@ -558,6 +563,7 @@ void Context::db_save(const char *path) {
     DbFileHeader h{};
     memcpy(h.magic, "HYDIADB1", 8);
     h.logN = (uint32_t)prm.logN; h.nQ = (uint32_t)nQ; h.dim = (uint32_t)prm.dim; h.packed = db_packed ? 1 : 0; h.kind = (uint32_t)db_kind;
+    h.babies = (uint32_t)db_babies;
     h.n_vectors = db_vectors; h.n_cts = db_cts; h.ct_bytes = db_layout().ct_bytes;
     for (int j = 0; j < nQ; j++) h.moduli[j] = q[j];
     if (fwrite(&h, sizeof h, 1, fc.f) != 1) throw std::runtime_error("hydia: write failed (header)");
@@ -580,6 +586,9 @@ void Context::db_load(const char *path) {
     if ((h.packed != 0) != db_packed || h.ct_bytes != db_layout().ct_bytes)
         throw std::runtime_error("hydia: database file layout (48-bit packed / 8-byte) differs from this context's");
     if (h.kind != 4 && h.kind != 5 && h.kind != 6) throw std::runtime_error("hydia: database file has an unknown packing kind");
+    if (h.kind == 6 && (h.babies < 2 || h.babies >= (uint32_t)prm.dim || (h.babies & (h.babies - 1)) || prm.dim % h.babies))
+        throw std::runtime_error("hydia: database file carries an invalid baby count");
+    if (h.kind == 5 && h.babies != 0 && h.babies != (uint32_t)prm.dim) throw std::runtime_error("hydia: database file header is inconsistent (kind 5 with a baby count)");
     // the header is untrusted input: the ciphertext count must be the one the packing implies for n_vectors (diagonal packing:
     // ceil(ceil(n / dim) / (slots / dim)) * dim; column packing: ceil(n / slots) * dim), and the file must hold exactly that many
     // — checked BEFORE anything is allocated or the resident database is touched
@@ -610,6 +619,7 @@ void Context::db_load(const char *path) {
         HIP_CHECK(hipMemcpy(d_db + off, buf.p, n, hipMemcpyHostToDevice));
     }
     db_kind = (int)h.kind;
+    db_babies = h.kind == 4 ? 0 : (h.babies ? (int)h.babies : prm.dim);
 }
 void Context::db_store(size_t t0, const u64 *d_plain, int X) {
     hk::db_pack(stream, N, nQ, d_plain, d_db + t0 * db_layout().ct_bytes, X, db_packed ? 1 : 0);

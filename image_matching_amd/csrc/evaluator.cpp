@@ -801,12 +801,19 @@ Ct Context::similarity(const Ct &qc) {
 // and the enroller has rotated diagonal i by -B (i div B) in the clear (database kind 6; same ciphertext order, so the inner sums
 // are loop B's own kernel on NG G "blocks" of B diagonals).  Per query B - 1 hoisted rotations instead of dim - 1; per block NG
 // relinearisations and NG - 1 ordinary rotations (rotation keys B, 2B, ..: already part of the key set) instead of one
-// relinearisation — the better trade while a GPU holds few blocks (Context::want_bsgs).  The reference itself hoists every
+// relinearisation — the better trade while a GPU holds few blocks; B grows with the blocks (Context::auto_babies) up to B = dim,
+// which is the reference's form.  The reference itself hoists every
 // rotation (sender_diag.cpp:22-26); SURVEY "fact 2" allows this form as long as decrypted scores stay within 1e-4, and the oracle
 // restates it (oracle/path.c hyo_compute_similarity_bsgs) so the ciphertexts are still checked bit for bit.
 void Context::build_giants() {
-    if (giants_valid) return;
-    const int B = bsgs_babies(), NG = (prm.dim + B - 1) / B;
+    const int B = db_babies, NG = (prm.dim + B - 1) / B;
+    if (giants_valid && giants_B == B) return;
+    if (d_giant_keys && giants_B != B) {  // another split: the tables change size
+        sync_all();
+        for (void *p : {(void *)d_giant_keys, (void *)d_giant_gal, (void *)d_giant_ginv}) (void)hipFree(p);
+        d_giant_keys = nullptr;
+        d_giant_gal = d_giant_ginv = nullptr;
+    }
     std::vector<const u64 *> ptrs(NG, nullptr);
     std::vector<unsigned> gal(NG, 1u), ginv(NG, 1u);
     for (int g = 1; g < NG; g++) {
@@ -828,12 +835,13 @@ void Context::build_giants() {
     HIP_CHECK(hipMemcpy(d_giant_gal, gal.data(), sizeof(unsigned) * NG, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_giant_ginv, ginv.data(), sizeof(unsigned) * NG, hipMemcpyHostToDevice));
     giants_valid = true;
+    giants_B = B;
 }
 Ct Context::similarity_bsgs_sum(const Ct &qc) {
     if (!d_db || db_cts == 0 || db_kind != 6) throw StateError("hydia: no database resident (pre-rotated diagonal packing)");
     if (qc.nl != nQ) throw StateError("hydia: query must be a fresh (level 0) ciphertext");
-    const int dim = prm.dim, B = bsgs_babies(), NG = (dim + B - 1) / B;
-    if (dim % B) throw std::runtime_error("hydia: the baby-step / giant-step mat-vec needs vector_dim to be a multiple of the baby count");
+    const int dim = prm.dim, B = db_babies, NG = (dim + B - 1) / B;
+    if (B < 1 || dim % B) throw StateError("hydia: the resident database carries no valid baby count");
     const int G = (int)(db_cts / dim), nl = nQ, nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     build_giants();
     // babies: rotations 0 .. B-1 of the query (loop A on B - 1 keys)

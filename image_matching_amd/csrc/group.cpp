@@ -28,7 +28,7 @@ struct hydia_group {
     std::vector<size_t> blk_lo, blk_hi;  // block range of each shard of the resident database
     size_t n_vectors = 0, n_blocks = 0;
     bool rot_split = true;  // loop A's rotations shared out over the active shards and exchanged (hydia_group_set_rotation_split)
-    bool bsgs = false;      // the resident database is in the baby-step / giant-step form: B - 1 rotations per query, nothing to share out
+    bool bsgs = false;      // the resident database is pre-rotated for fewer than vector_dim babies: loop A is short, nothing is shared out
 };
 
 namespace {
@@ -307,8 +307,8 @@ int hydia_group_db_enroll(hydia_group *g, double *db, size_t n, const uint8_t se
     // are the ciphertexts a single context of that form computes
     size_t max_blocks = 0;
     for (uint32_t r = 0; r < R; r++) max_blocks = std::max(max_blocks, g->blk_hi[r] - g->blk_lo[r]);
-    const bool bsgs = g->shard[0]->cx.want_bsgs(max_blocks);
-    g->bsgs = bsgs;
+    const int babies = g->shard[0]->cx.babies_for(max_blocks);
+    g->bsgs = babies < (int)dim;
     on_shards(g, all, [&](uint32_t r) {
         Context &cx = g->shard[r]->cx;
         const size_t first = g->blk_lo[r] * S, last = std::min(g->blk_hi[r] * S, n);
@@ -320,8 +320,9 @@ int hydia_group_db_enroll(hydia_group *g, double *db, size_t n, const uint8_t se
         const size_t nl = last - first;
         const size_t per = S / dim, nblk = (nl + dim - 1) / dim;
         cx.db_resize(nl, ((nblk + per - 1) / per) * dim);
-        client_enroll(cx, db + first * dim, nl, seed, g->blk_lo[r], bsgs);
-        cx.db_kind = bsgs ? 6 : 5;
+        client_enroll(cx, db + first * dim, nl, seed, g->blk_lo[r], babies);
+        cx.db_kind = babies < (int)dim ? 6 : 5;
+        cx.db_babies = babies;
     });
     return HYDIA_OK;
     API_END

@@ -23,8 +23,6 @@ struct StateError : std::runtime_error {   // missing key / database / wrong lev
 };
 }  // namespace hydia
 
-#define HY_BSGS_MAX_BLOCKS 4
-
 #define HIP_CHECK(expr)                                                                                   \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \
@@ -159,21 +157,40 @@ struct Context : HostParams {
     unsigned char *d_db = nullptr;
     size_t db_vectors = 0, db_cts = 0;
     int db_kind = 0;   // 0 none, 5 diagonal packing (HyDia, approach 5), 6 the same with pre-rotated diagonals (BSGS mat-vec), 4 column packing (HERS)
-    // Which form of the diagonal mat-vec a database enrolled on this context gets (HYDIA_MATVEC=auto|hoisted|bsgs, hydia_set_matvec):
-    //   hoisted  the reference's: dim - 1 hoisted rotations of the query, one tensor-accumulate over all diagonals of a block
-    //   bsgs     baby-step / giant-step (north_star): B - 1 hoisted rotations, dim / B relinearisations + giant rotations per block
-    //   auto     bsgs while this context holds at most HY_BSGS_MAX_BLOCKS blocks (the per-block giant steps then cost less than the
-    //            per-query babies they save), hoisted above
-    int matvec_mode = 0;  // 0 auto, 1 hoisted, 2 bsgs
-    bool want_bsgs(size_t blocks) const { return matvec_mode == 2 || (matvec_mode == 0 && blocks >= 1 && blocks <= HY_BSGS_MAX_BLOCKS); }
+    int db_babies = 0; // kind 5 / 6: hoisted (baby) rotations the resident database was enrolled for; == vector_dim for kind 5
+    // Which form of the diagonal mat-vec a database enrolled on this context gets (HYDIA_MATVEC=auto|hoisted|bsgs|<B>, hydia_set_matvec).
+    // With i = b + B g: B - 1 hoisted rotations of the query per QUERY, dim / B relinearisations + dim / B - 1 giant rotations per BLOCK.
+    //   hoisted  B = dim: the reference's own form (dim - 1 hoisted rotations, one relinearisation per block, no giant step)
+    //   bsgs     B = the smallest power of two with B^2 >= dim (32 at dim 512): the classic baby-step / giant-step split
+    //   <B>      any power of two dividing dim
+    //   auto     B grows with the blocks this context holds (auto_babies): few blocks -> few babies, many blocks -> hoisted
+    int matvec_mode = 0;  // 0 auto, 1 hoisted, otherwise the baby count
     int bsgs_babies() const {
         int B = 1;
         while (B * B < prm.dim) B <<= 1;
         return B;
     }
+    // measured on MI355X (profiles/r03/matvec_sweep.txt: every split at 1 .. 32 blocks): a baby costs ~12 us per query, a giant step
+    // (relinearisation or rotation of one partial sum) ~30 us per block — 64 babies win up to 3 blocks, 128 up to 12, 256 up to 24
+    int auto_babies(size_t blocks) const {
+        const int base = bsgs_babies();
+        static const struct { size_t limit; int mult; } rule[] = {{3, 2}, {12, 4}, {24, 8}};  // 64 / 128 / 256 babies at dim 512
+        for (const auto &r : rule)
+            if (blocks <= r.limit) return std::min(prm.dim, base * r.mult);
+        return prm.dim;
+    }
+    // babies of an enrolment of `blocks` blocks; explicit > 0 overrides the context's policy (1 = hoisted)
+    int babies_for(size_t blocks, int explicit_mode = 0) const {
+        const int m = explicit_mode ? explicit_mode : matvec_mode;
+        if (m == 0) return auto_babies(blocks);
+        if (m == 1) return prm.dim;
+        if (m < 2 || m > prm.dim || (m & (m - 1)) || prm.dim % m) throw std::runtime_error("hydia: the baby count must be a power of two dividing vector_dim");
+        return m;
+    }
     const u64 **d_giant_keys = nullptr;  // device arrays over g = 0 .. dim/B - 1: key, Galois element and inverse of rotation B g
     unsigned *d_giant_gal = nullptr, *d_giant_ginv = nullptr;
     bool giants_valid = false;
+    int giants_B = 0;
     void build_giants();
     bool db_packed = true;
     DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }

@@ -117,8 +117,9 @@ def load_library():
         "hydia_set_matvec": (i32, [vp, i32]),
         "hydia_get_matvec": (i32, [vp]),
         "hydia_db_kind": (i32, [vp]),
-        "hydia_db_set_kind": (i32, [vp, i32]),
-        "hydia_bsgs_max_blocks": (sz, []),
+        "hydia_db_babies": (i32, [vp]),
+        "hydia_db_set_babies": (i32, [vp, i32]),
+        "hydia_auto_babies": (i32, [vp, sz]),
         "hydia_random_seed": (i32, [vp]),
         "hydia_shard_blocks": (None, [sz, u32, u32, C.POINTER(sz), C.POINTER(sz)]),
         "hydia_group_create": (i32, [C.POINTER(_Params), C.POINTER(i32), u32, pp]),
@@ -198,11 +199,6 @@ def default_params(**over):
     for k, v in over.items():
         setattr(p, k, v)
     return p
-
-
-def bsgs_max_blocks():
-    """blocks per context up to which "auto" picks the baby-step / giant-step mat-vec"""
-    return int(load_library().hydia_bsgs_max_blocks())
 
 
 def compute_required_depth(approach):
@@ -472,18 +468,29 @@ class Context:
     def db_load(self, path):
         _chk(self.L.hydia_db_load(self.h, str(path).encode()))
 
-    # ---- the two forms of the diagonal mat-vec (include/hydia.h): "auto" | "hoisted" | "bsgs"; takes effect at the next enrolment
-    MATVEC = {"auto": 0, "hoisted": 1, "bsgs": 2}
+    # ---- the split of the diagonal mat-vec (include/hydia.h): "auto" | "hoisted" | "bsgs" | a baby count; takes effect at the next enrolment
+    def _matvec_code(self, mode):
+        if isinstance(mode, str):
+            return {"auto": 0, "hoisted": 1, "bsgs": self.bsgs_babies()}[mode]
+        return int(mode)
 
     def set_matvec(self, mode):
-        _chk(self.L.hydia_set_matvec(self.h, self.MATVEC[mode] if isinstance(mode, str) else int(mode)))
+        _chk(self.L.hydia_set_matvec(self.h, self._matvec_code(mode)))
 
     def get_matvec(self):
-        return {v: k for k, v in self.MATVEC.items()}[self.L.hydia_get_matvec(self.h)]
+        m = self.L.hydia_get_matvec(self.h)
+        return {0: "auto", 1: "hoisted"}.get(m, m)
 
     def db_kind(self):
         """0 none, 5 hoisted diagonals, 6 pre-rotated diagonals (baby-step / giant-step), 4 HERS columns"""
         return int(self.L.hydia_db_kind(self.h))
+
+    def db_babies(self):
+        """hoisted rotations per query the resident diagonal database is laid out for (vector_dim = the reference's form)"""
+        return int(self.L.hydia_db_babies(self.h))
+
+    def db_set_babies(self, babies):
+        _chk(self.L.hydia_db_set_babies(self.h, int(babies)))
 
     def bsgs_babies(self):
         B = 1
@@ -491,13 +498,9 @@ class Context:
             B *= 2
         return B
 
-    def db_set_kind(self, kind):
-        _chk(self.L.hydia_db_set_kind(self.h, int(kind)))
-
-    def want_bsgs(self, blocks):
-        """what an enrolment of `blocks` 16384-vector blocks on this context would choose"""
-        m = self.L.hydia_get_matvec(self.h)
-        return m == 2 or (m == 0 and 1 <= blocks <= int(self.L.hydia_bsgs_max_blocks()))
+    def auto_babies(self, blocks):
+        """what an enrolment of `blocks` 16384-vector blocks on this context would pick (its policy applied)"""
+        return int(self.L.hydia_auto_babies(self.h, blocks))
 
     def db_stats(self):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
@@ -534,10 +537,10 @@ class DiagonalEnroller:
         """DiagonalEnroller::serializeDB (src/enroller/enroller_diag.cpp:12-53).  Normalises `database` IN PLACE like
         the reference; the ciphertexts go straight into HBM instead of serial/db_diagonal/index<t>.bin.  first_block > 0:
         `database` is one shard (a contiguous range of 16384-vector blocks) of a larger database.  matvec: None = the context's
-        policy (Context.set_matvec), or "hoisted" / "bsgs" (a sharded enrolment passes one decision to every shard)."""
+        policy (Context.set_matvec), or "hoisted" / "bsgs" / a baby count (a sharded enrolment passes one decision to every shard)."""
         assert database.dtype == np.float64 and database.flags.c_contiguous
         assert database.shape == (self.numVectors, self.cc.dim)
-        mv = 0 if matvec is None else Context.MATVEC[matvec]
+        mv = 0 if matvec is None else self.cc._matvec_code(matvec)
         _chk(self.cc.L.hydia_db_enroll_shard_ex(self.cc.h, _p(database), self.numVectors, _p(_seed(seed)), first_block, mv))
 
 

@@ -39,11 +39,11 @@ def shard_vectors(n_total, slots, world, rank):
     return min(blo * slots, n_total), min(bhi * slots, n_total)
 
 
-def group_wants_bsgs(cc, n_total, world):
-    """ONE form of the mat-vec for a sharded database (include/hydia.h, hydia_set_matvec): the context's policy applied to the LARGEST
-    shard — every rank computes the same answer from (n_total, world) and its own (identically configured) context, no exchange."""
+def group_babies(cc, n_total, world):
+    """ONE split of the mat-vec for a sharded database (include/hydia.h, hydia_set_matvec): the context's policy applied to the
+    LARGEST shard — every rank computes the same answer from (n_total, world) and its own (identically configured) context."""
     G = -(-n_total // cc.slots)
-    return cc.want_bsgs(max(hi - lo for lo, hi in (shard_blocks(G, world, r) for r in range(world))))
+    return cc.auto_babies(max(hi - lo for lo, hi in (shard_blocks(G, world, r) for r in range(world))))
 
 
 # ------------------------------------------------------------------ one process, R contexts
@@ -129,14 +129,14 @@ class DistDiagonalEnroller:
     def __init__(self, cc, n_total, rank, world):
         self.cc, self.n_total, self.rank, self.world = cc, n_total, rank, world
         self.first, self.last = shard_vectors(n_total, cc.slots, world, rank)
-        self.bsgs = group_wants_bsgs(cc, n_total, world)
+        self.babies = group_babies(cc, n_total, world)
 
     def serializeDB(self, rows, seed=None):
         n_local = self.last - self.first
         assert rows.shape == (n_local, self.cc.dim)
         if n_local:
             _h.DiagonalEnroller(self.cc, n_local).serializeDB(rows, seed=seed, first_block=self.first // self.cc.slots,
-                                                              matvec="bsgs" if self.bsgs else "hoisted")
+                                                              matvec="hoisted" if self.babies >= self.cc.dim else self.babies)
 
 
 class DistDiagonalSender:
@@ -167,7 +167,7 @@ class DistDiagonalSender:
         self.active = [r for r, (lo, hi) in enumerate(self.ranges) if hi > lo]
         K = len(self.active)
         # the baby-step / giant-step form needs B - 1 rotations per query: nothing worth sharing out
-        self.bsgs = hasattr(cc, "want_bsgs") and group_wants_bsgs(cc, n_total, world)
+        self.bsgs = hasattr(cc, "auto_babies") and group_babies(cc, n_total, world) < cc.dim
         self.rotation_split = bool(rotation_split) and world > 1 and K > 1 and not self.bsgs
         self.rot_ranges = {r: shard_blocks(cc.dim, K, k) for k, r in enumerate(self.active)}
         self.rot_even = K > 0 and cc.dim % K == 0 and K == world  # every rank holds blocks and the ranges are equal: in-place all_gather

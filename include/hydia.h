@@ -146,21 +146,27 @@ int hydia_db_enroll(hydia_ctx *ctx, double *db /* n x vector_dim row-major */, s
  * this shard's rows and first_block is the index of its first block in the whole database, so the shard encrypts with exactly
  * the nonces the unsharded enrolment uses for those blocks (bit-identical ciphertexts). */
 int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block);
-/* ---- the two forms of the diagonalised mat-vec.  hoisted = the reference's own (src/sender/sender_diag.cpp:22-26:
- * vector_dim - 1 hoisted rotations of the query, one relinearisation per block); bsgs = baby-step / giant-step (BASELINE.json's
- * north_star): the enroller rotates diagonal i by -B (i div B) slots in the clear (B = 32 babies at vector_dim 512; same ciphertext
- * order and nonces), the sender needs B - 1 hoisted rotations per query and vector_dim / B relinearisations + giant rotations per
- * block.  Decrypted results agree within CKKS noise (1e-4 on scores); ciphertexts are bit-identical between runs of the same form.
- * mode: 0 auto (bsgs while the enrolling context holds at most hydia_bsgs_max_blocks() blocks), 1 hoisted, 2 bsgs; initial value from
- * HYDIA_MATVEC=auto|hoisted|bsgs.  It takes effect at the NEXT enrolment; hydia_db_kind tells what is resident (0 none, 5 hoisted
- * diagonals, 6 pre-rotated diagonals, 4 HERS columns).  Ciphertexts imported one by one (hydia_db_import_ct: the reference's
- * enroller) are always kind 5. */
+/* ---- the split of the diagonalised mat-vec.  With rotation i = b + B g: B - 1 hoisted ("baby") rotations of the
+ * query per QUERY, vector_dim / B relinearised partial sums per BLOCK of which all but the first are rotated by B g ("giant" steps,
+ * ordinary key switches with the rotation keys B, 2B, .. that src/main.cpp:195-206 already generates).  The enroller rotates
+ * diagonal i by -B (i div B) slots in the clear; ciphertext order and nonces do not change.
+ *   B = vector_dim      "hoisted": the reference's own form (src/sender/sender_diag.cpp:22-26), no pre-rotation, no giant step
+ *   B = 32 (dim 512)    "bsgs": the classic square-root split BASELINE.json's north_star names
+ *   any power of two dividing vector_dim in between
+ * Decrypted results agree within CKKS noise (1e-4 on scores) whatever B; ciphertexts are bit-identical between runs with the same B.
+ * hydia_set_matvec mode: 0 auto (hydia_auto_babies: B grows with the blocks the enrolling context holds — at vector_dim 512: 64 up
+ * to 3 blocks, 128 up to 12, 256 up to 24, hoisted above; measured, profiles/r03/matvec_sweep.txt), 1 hoisted, otherwise B itself; initial value from HYDIA_MATVEC=auto|hoisted|bsgs|<B>.
+ * It takes effect at the NEXT enrolment; hydia_db_kind / hydia_db_babies tell what is resident (kind 0 none, 5 hoisted diagonals,
+ * 6 pre-rotated diagonals, 4 HERS columns).  Ciphertexts imported one by one (hydia_db_alloc + hydia_db_import_ct: the reference
+ * enroller's) are taken as hoisted unless hydia_db_set_babies says otherwise. */
 int hydia_set_matvec(hydia_ctx *ctx, int mode);
 int hydia_get_matvec(const hydia_ctx *ctx);
 int hydia_db_kind(const hydia_ctx *ctx);
-int hydia_db_set_kind(hydia_ctx *ctx, int kind); /* form of an IMPORTED database (hydia_db_alloc + hydia_db_import_ct assume 5) */
-size_t hydia_bsgs_max_blocks(void);
-/* hydia_db_enroll_shard with an explicit form (0 = the context's policy): a sharded enrolment passes ONE decision to every shard */
+int hydia_db_babies(const hydia_ctx *ctx);
+int hydia_db_set_babies(hydia_ctx *ctx, int babies);
+int hydia_auto_babies(const hydia_ctx *ctx, size_t blocks); /* what an enrolment of `blocks` blocks on this context would pick */
+/* hydia_db_enroll_shard with an explicit split (0 = the context's policy, 1 = hoisted, else B): a sharded enrolment passes ONE
+ * decision to every shard */
 int hydia_db_enroll_shard_ex(hydia_ctx *ctx, double *db, size_t n, const uint8_t seed[32], size_t first_block, int matvec);
 /* or load ciphertexts produced elsewhere: t = block*vector_dim + diagonal, i.e. serial/db_diagonal/index<t>.bin
  * (src/enroller/enroller_diag.cpp:161; read back at src/sender/sender_diag.cpp:87-91) */

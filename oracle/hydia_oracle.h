@@ -151,11 +151,12 @@ hy_ct **hyo_index_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q,
 hy_ct *hyo_membership_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n);
 /* baby-step / giant-step form (path.c): pre-rotated diagonals at enrolment, B - 1 hoisted rotations + dim / B giant steps per block */
 int hyo_bsgs_babies(const hy_params *p);
-void hyo_enroll_layout_row_bsgs(const hy_params *p, const double *db_norm, size_t n, size_t t, double *slots);
-hy_ct **hyo_enroll_bsgs(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts);
-hy_ct **hyo_compute_similarity_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out);
-hy_ct **hyo_index_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out);
-hy_ct *hyo_membership_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n);
+/* B = babies: a power of two dividing dim (hyo_bsgs_babies gives the classic square-root split; B = dim is the hoisted form) */
+void hyo_enroll_layout_row_bsgs(const hy_params *p, const double *db_norm, size_t n, size_t t, double *slots, int B);
+hy_ct **hyo_enroll_bsgs(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts, int B);
+hy_ct **hyo_compute_similarity_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out, int B);
+hy_ct **hyo_index_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out, int B);
+hy_ct *hyo_membership_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, int B);
 /* the reference's per-ciphertext file hand-off (enroller_diag.cpp:158-166, sender_diag.cpp:85-94); own raw format */
 int hyo_db_write_files(const hy_params *p, hy_ct **db, size_t count, const char *dir);
 hy_ct **hyo_index_scenario_files(const hy_params *p, const hy_keys *k, const hy_ct *q, const char *dir, size_t n, size_t *n_out);

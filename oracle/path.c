@@ -445,19 +445,22 @@ hy_ct **hyo_index_scenario(const hy_params *p, const hy_keys *k, const hy_ct *q,
  * sender needs B - 1 hoisted rotations of the query instead of dim - 1, relinearises the dim / B partial sums of a block and
  * rotates them by B g (ordinary key switches with the rotation keys B, 2B, ...), adds, rescales.  Worth it while the blocks on a
  * GPU are few (the per-block giant steps cost more than the per-query babies they replace beyond ~4 blocks). */
+/* smallest power of two B with B*B >= dim: the classic split (32 babies x 16 giants at dim 512).  Any power of two B dividing dim
+ * is a valid split — more babies cost rotations per QUERY, fewer giants save key switches per BLOCK — and B = dim is the
+ * reference's own all-hoisted form (no pre-rotation, no giant step). */
 int hyo_bsgs_babies(const hy_params *p) {
     int B = 1;
     while (B * B < p->dim) B <<= 1;
     return B;
 }
-void hyo_enroll_layout_row_bsgs(const hy_params *p, const double *db, size_t n, size_t t, double *slots) {
-    size_t S = p->slots, i = t % p->dim, sh = (size_t)hyo_bsgs_babies(p) * (i / hyo_bsgs_babies(p));
+void hyo_enroll_layout_row_bsgs(const hy_params *p, const double *db, size_t n, size_t t, double *slots, int B) {
+    size_t S = p->slots, i = t % p->dim, sh = (size_t)B * (i / (size_t)B);
     double *plain = (double *)malloc(sizeof(double) * S);
     hyo_enroll_layout_row(p, db, n, t, plain);
     for (size_t s = 0; s < S; s++) slots[s] = plain[(s + S - sh % S) % S]; /* Rot_{-sh}: slot s takes slot s - sh */
     free(plain);
 }
-hy_ct **hyo_enroll_bsgs(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts) {
+hy_ct **hyo_enroll_bsgs(const hy_params *p, const hy_keys *k, double *db, size_t n, const uint8_t seed[32], size_t *n_cts, int B) {
     size_t dim = p->dim;
 #pragma omp parallel for
     for (size_t v = 0; v < n; v++) hyo_normalize(db + v * dim, (int)dim);
@@ -466,15 +469,15 @@ hy_ct **hyo_enroll_bsgs(const hy_params *p, const hy_keys *k, double *db, size_t
 #pragma omp parallel for schedule(dynamic)
     for (size_t t = 0; t < T; t++) {
         double *slots = (double *)malloc(sizeof(double) * p->slots);
-        hyo_enroll_layout_row_bsgs(p, db, n, t, slots);
+        hyo_enroll_layout_row_bsgs(p, db, n, t, slots, B);
         out[t] = hyo_encrypt(p, k, slots, p->slots, seed, DB_NONCE_BASE + t);
         free(slots);
     }
     *n_cts = T;
     return out;
 }
-hy_ct **hyo_compute_similarity_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out) {
-    const int dim = p->dim, N = p->N, B = hyo_bsgs_babies(p), NG = (dim + B - 1) / B;
+hy_ct **hyo_compute_similarity_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out, int B) {
+    const int dim = p->dim, N = p->N, NG = (dim + B - 1) / B;
     size_t G = (n + p->slots - 1) / p->slots;
     hy_ct **rot = (hy_ct **)calloc(B, sizeof(hy_ct *));
     rot[0] = hyo_ct_clone(p, q);
@@ -516,8 +519,8 @@ hy_ct **hyo_compute_similarity_bsgs(const hy_params *p, const hy_keys *k, const 
     *n_out = G;
     return sim;
 }
-hy_ct **hyo_index_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out) {
-    hy_ct **score = hyo_compute_similarity_bsgs(p, k, q, db, n, n_out);
+hy_ct **hyo_index_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, size_t *n_out, int B) {
+    hy_ct **score = hyo_compute_similarity_bsgs(p, k, q, db, n, n_out, B);
 #pragma omp parallel for
     for (size_t i = 0; i < *n_out; i++) {
         hy_ct *c = hyo_chebyshev_compare(p, k, score[i], MATCH_THRESHOLD, COMP_DEPTH);
@@ -526,9 +529,9 @@ hy_ct **hyo_index_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_c
     }
     return score;
 }
-hy_ct *hyo_membership_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n) {
+hy_ct *hyo_membership_scenario_bsgs(const hy_params *p, const hy_keys *k, const hy_ct *q, hy_ct **db, size_t n, int B) {
     size_t G;
-    hy_ct **score = hyo_index_scenario_bsgs(p, k, q, db, n, &G);
+    hy_ct **score = hyo_index_scenario_bsgs(p, k, q, db, n, &G, B);
     hy_ct *m = score[0];
     for (size_t i = 1; i < G; i++) {
         hyo_add_inplace(p, m, score[i]);

@@ -13,7 +13,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB = None
 
-BSGS_MAX_BLOCKS = 4  # the product's auto rule (include/hydia.h hydia_bsgs_max_blocks): mirrored so that oracle and GPU pick the same form
+def auto_babies(dim, blocks):
+    """Mirror of the product's auto rule (include/hydia.h hydia_auto_babies; asserted equal in tests/test_gpu_parity.py): how many
+    hoisted (baby) rotations of the query a database of `blocks` 16384-vector blocks is enrolled for.  dim = the reference's own form."""
+    base = 1
+    while base * base < dim:
+        base *= 2
+    for limit, mult in ((3, 2), (12, 4), (24, 8)):
+        if blocks <= limit:
+            return min(dim, base * mult)
+    return dim
+
 
 u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
@@ -94,11 +104,11 @@ def lib():
         "hyo_index_scenario": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
         "hyo_membership_scenario": (vp, [vp, vp, vp, vp, C.c_size_t]),
         "hyo_bsgs_babies": (C.c_int, [vp]),
-        "hyo_enroll_layout_row_bsgs": (None, [vp, vp, C.c_size_t, C.c_size_t, vp]),
-        "hyo_enroll_bsgs": (vp, [vp, vp, vp, C.c_size_t, vp, vp]),
-        "hyo_compute_similarity_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
-        "hyo_index_scenario_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, vp]),
-        "hyo_membership_scenario_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t]),
+        "hyo_enroll_layout_row_bsgs": (None, [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_int]),
+        "hyo_enroll_bsgs": (vp, [vp, vp, vp, C.c_size_t, vp, vp, C.c_int]),
+        "hyo_compute_similarity_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, vp, C.c_int]),
+        "hyo_index_scenario_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, vp, C.c_int]),
+        "hyo_membership_scenario_bsgs": (vp, [vp, vp, vp, vp, C.c_size_t, C.c_int]),
         "hyo_db_write_files": (C.c_int, [vp, vp, C.c_size_t, C.c_char_p]),
         "hyo_index_scenario_files": (vp, [vp, vp, vp, C.c_char_p, C.c_size_t, vp]),
         "hyo_decrypt_membership": (C.c_int, [vp, vp, vp]),
@@ -391,18 +401,31 @@ class Oracle:
         return Ct(self.P, self.L.hyo_chebyshev_compare(self.P.h, self.K.h, ct.h, delta, depth))
 
     # ---- roles
+    def babies_for(self, n, matvec=None):
+        """matvec: None = the product's auto rule, "hoisted" (the reference's form: every rotation hoisted), "bsgs" (the classic
+        square-root split) or an explicit baby count (a power of two dividing vector_dim)"""
+        if matvec is None:
+            return auto_babies(self.P.dim, -(-n // self.P.slots))
+        if matvec == "hoisted":
+            return self.P.dim
+        if matvec == "bsgs":
+            return int(self.L.hyo_bsgs_babies(self.P.h))
+        return int(matvec)
+
     def enroll(self, db, seed, matvec=None):
-        """DiagonalEnroller::serializeDB — normalises `db` in place (like the reference).  matvec: "hoisted" (the reference's form),
-        "bsgs" (pre-rotated diagonals for the baby-step / giant-step mat-vec) or None = the product's auto rule: bsgs while the
-        database has at most BSGS_MAX_BLOCKS blocks.  The returned array remembers its form; the sender methods follow it."""
+        """DiagonalEnroller::serializeDB — normalises `db` in place (like the reference).  The returned array remembers its baby
+        count (`.babies`; vector_dim = the reference's hoisted form, less = pre-rotated diagonals for the baby-step / giant-step
+        mat-vec); the sender methods follow it."""
         assert db.dtype == np.float64 and db.flags.c_contiguous and db.shape[1] == self.P.dim
-        G = -(-db.shape[0] // self.P.slots)
-        bsgs = (G <= BSGS_MAX_BLOCKS) if matvec is None else {"hoisted": False, "bsgs": True}[matvec]
+        B = self.babies_for(db.shape[0], matvec)
         n_out = C.c_size_t(0)
-        fn = self.L.hyo_enroll_bsgs if bsgs else self.L.hyo_enroll
-        h = fn(self.P.h, self.K.h, _ptr(db), db.shape[0], _ptr(seed_bytes(seed)), C.byref(n_out))
+        if B >= self.P.dim:
+            h = self.L.hyo_enroll(self.P.h, self.K.h, _ptr(db), db.shape[0], _ptr(seed_bytes(seed)), C.byref(n_out))
+        else:
+            h = self.L.hyo_enroll_bsgs(self.P.h, self.K.h, _ptr(db), db.shape[0], _ptr(seed_bytes(seed)), C.byref(n_out), B)
         arr = CtArray(self.P, h, n_out.value)
-        arr.bsgs = bsgs
+        arr.babies = B
+        arr.bsgs = B < self.P.dim
         return arr
 
     def encrypt_query(self, query, seed, nonce=1):
@@ -414,19 +437,24 @@ class Oracle:
 
     def compute_similarity(self, q, db, n):
         n_out = C.c_size_t(0)
-        fn = self.L.hyo_compute_similarity_bsgs if getattr(db, "bsgs", False) else self.L.hyo_compute_similarity
-        h = fn(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
+        if getattr(db, "bsgs", False):
+            h = self.L.hyo_compute_similarity_bsgs(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out), db.babies)
+        else:
+            h = self.L.hyo_compute_similarity(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
         return CtArray(self.P, h, n_out.value)
 
     def index_scenario(self, q, db, n):
         n_out = C.c_size_t(0)
-        fn = self.L.hyo_index_scenario_bsgs if getattr(db, "bsgs", False) else self.L.hyo_index_scenario
-        h = fn(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
+        if getattr(db, "bsgs", False):
+            h = self.L.hyo_index_scenario_bsgs(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out), db.babies)
+        else:
+            h = self.L.hyo_index_scenario(self.P.h, self.K.h, q.h, db.h, n, C.byref(n_out))
         return CtArray(self.P, h, n_out.value)
 
     def membership_scenario(self, q, db, n):
-        fn = self.L.hyo_membership_scenario_bsgs if getattr(db, "bsgs", False) else self.L.hyo_membership_scenario
-        return Ct(self.P, fn(self.P.h, self.K.h, q.h, db.h, n))
+        if getattr(db, "bsgs", False):
+            return Ct(self.P, self.L.hyo_membership_scenario_bsgs(self.P.h, self.K.h, q.h, db.h, n, db.babies))
+        return Ct(self.P, self.L.hyo_membership_scenario(self.P.h, self.K.h, q.h, db.h, n))
 
     def write_db_files(self, db, directory):
         """one index<t>.bin per ciphertext (enroller_diag.cpp:158-166)"""

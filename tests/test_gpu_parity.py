@@ -40,8 +40,8 @@ def load_db(cc, dbc, n):
     assert cc.db_num_cts(n) == len(dbc)
     for t in range(len(dbc)):
         cc.db_import_ct(t, dbc[t].data())
-    if getattr(dbc, "bsgs", False):  # the oracle enrolled in the baby-step / giant-step form
-        cc.db_set_kind(6)
+    if getattr(dbc, "bsgs", False):  # the oracle enrolled pre-rotated diagonals (baby-step / giant-step split)
+        cc.db_set_babies(dbc.babies)
 
 
 @pytest.fixture(scope="module")
@@ -151,6 +151,22 @@ def test_comparator_depths_and_guard(small):
         assert np.array_equal(cc.chebyshev_compare(g, 0.44, depth).export()[0], Or.chebyshev_compare(ct, 0.44, depth).data())
     same = cc.chebyshev_compare(g, 0.44, 6)  # openFHE_wrapper.cpp:146-149
     assert np.array_equal(same.export()[0], ct.data())
+
+
+def test_auto_rule_is_mirrored_by_the_oracle_helper(im):
+    """tests/oracle_lib.auto_babies (what Or.enroll(matvec=None) uses) == the product's rule (hydia_auto_babies) for both rings, so a
+    test that lets both sides choose compares like with like"""
+    for prm, dim in ((im.default_params(), 512), (im.default_params(log_n=11, vector_dim=64), 64)):
+        cc = im.Context(prm, 0)
+        for blocks in list(range(1, 70)) + [100, 1000]:
+            assert cc.auto_babies(blocks) == O.auto_babies(dim, blocks), (dim, blocks)
+        cc.set_matvec("hoisted")
+        assert cc.auto_babies(1) == dim and cc.get_matvec() == "hoisted"
+        cc.set_matvec(dim // 4)
+        assert cc.auto_babies(50) == dim // 4
+        with pytest.raises(im.HydiaError):
+            cc.set_matvec(48)  # not a power of two dividing vector_dim
+        cc.close()
 
 
 def test_comparator_depths_11_to_15(im):

@@ -506,6 +506,7 @@ def test_shard_group_full_size_2p20(im):
     query = np.ones(512)
     prm = im.default_params()
     cc = im.Context(prm, 0)
+    cc.set_matvec("hoisted")  # one split on both sides: "auto" would give the 8-block shards 128 babies and the 64-block context 512
     cc.keygen(31)
     a = db.copy()
     im.DiagonalEnroller(cc, n).serializeDB(a, seed=8)
@@ -518,9 +519,9 @@ def test_shard_group_full_size_2p20(im):
     del q, idx
     cc.close()
     grp = im.ShardGroup([0] * 8, prm)  # config 5's own shape: 8 shards of 8 blocks (here all on the one GPU; keys resident once)
+    grp.ctx0.set_matvec("hoisted")
     grp.keygen(31)
-    im.ShardedDiagonalEnroller(grp, n).serializeDB(db, seed=8)
-    del db
+    im.ShardedDiagonalEnroller(grp, n).serializeDB(db.copy(), seed=8)
     assert grp.shard_range(0) == (0, n // 8) and grp.shard_range(7) == (7 * (n // 8), n // 8)
     gr, gs = im.DiagonalReceiver(grp.ctx0, n), im.ShardedDiagonalSender(grp, n)
     gq = gr.encryptQuery(query, seed=2, nonce=9)
@@ -530,5 +531,15 @@ def test_shard_group_full_size_2p20(im):
     assert gr.decryptIndex(gidx) == planted
     gmem = gs.membershipScenario(gq)
     assert np.array_equal(gmem.export(), want_mem) and gr.decryptMembership(gmem) is True
-    del gq, gidx, gmem
+    del gidx, gmem
+    # the same database under the DEFAULT policy: 8 blocks per shard -> 128 babies + 4 giant steps per block (pre-rotated diagonals).
+    # Other ciphertexts, the same answers
+    grp.ctx0.set_matvec("auto")
+    im.ShardedDiagonalEnroller(grp, n).serializeDB(db, seed=8)
+    del db
+    assert grp.shard_ctx(3).db_kind() == 6 and grp.shard_ctx(3).db_babies() == grp.ctx0.auto_babies(8) == 128
+    gidx = gs.indexScenario(gq)
+    assert len(gidx) == 64 and gr.decryptIndex(gidx) == planted
+    assert gr.decryptMembership(gs.membershipScenario(gq)) is True
+    del gq, gidx
     grp.close()

@@ -52,7 +52,7 @@ def test_normalize_matches_reference_semantics(small_params):
     assert not z.any()
 
 
-@pytest.mark.parametrize("matvec", ["hoisted", "bsgs"])
+@pytest.mark.parametrize("matvec", ["hoisted", "bsgs", 16])
 @pytest.mark.parametrize("n,matches", [(1500, [0, 700, 1499]), (64, [63]), (1, [0]), (1024, []), (1025, [1024])])
 def test_hydia_path_small_ring(small_params, small_keys, n, matches, matvec):
     """both forms of the mat-vec: the reference's hoisted rotations and the baby-step / giant-step restatement (pre-rotated diagonals)"""
@@ -89,9 +89,10 @@ def test_bsgs_layout_is_the_hoisted_layout_rotated_in_the_clear(small_params):
     plain, rot = np.zeros(P.slots), np.zeros(P.slots)
     for t in (0, 7, 8, 9, 63, 64 + 17, 64 + 63):
         P.L.hyo_enroll_layout_row(P.h, db.ctypes.data, n, t, plain.ctypes.data)
-        P.L.hyo_enroll_layout_row_bsgs(P.h, db.ctypes.data, n, t, rot.ctypes.data)
-        sh = B * ((t % P.dim) // B)
-        assert np.array_equal(rot, np.roll(plain, sh)), t  # slot s takes slot s - sh
+        for Bx in (B, 2 * B, P.dim):  # the square-root split, a coarser one, and B = dim = the reference layout itself
+            P.L.hyo_enroll_layout_row_bsgs(P.h, db.ctypes.data, n, t, rot.ctypes.data, Bx)
+            sh = Bx * ((t % P.dim) // Bx)
+            assert np.array_equal(rot, np.roll(plain, sh)), (t, Bx)  # slot s takes slot s - sh
 
 
 def test_zero_vector_row_and_enroll_normalises_in_place(small_params, small_keys):
