@@ -805,37 +805,45 @@ Ct Context::similarity(const Ct &qc) {
 // which is the reference's form.  The reference itself hoists every
 // rotation (sender_diag.cpp:22-26); SURVEY "fact 2" allows this form as long as decrypted scores stay within 1e-4, and the oracle
 // restates it (oracle/path.c hyo_compute_similarity_bsgs) so the ciphertexts are still checked bit for bit.
-void Context::build_giants() {
-    const int B = db_babies, NG = (prm.dim + B - 1) / B;
-    if (giants_valid && giants_B == B) return;
-    if (d_giant_keys && giants_B != B) {  // another split: the tables change size
+void Context::build_giants(int G) {
+    const int B = db_babies, NG = (prm.dim + B - 1) / B, X = (NG - 1) * G;
+    if (giants_valid && giants_B == B && giants_G == G) return;
+    if (d_giant_keys) {  // another split or block count: the tables change size
         sync_all();
         for (void *p : {(void *)d_giant_keys, (void *)d_giant_gal, (void *)d_giant_ginv}) (void)hipFree(p);
         d_giant_keys = nullptr;
         d_giant_gal = d_giant_ginv = nullptr;
     }
-    std::vector<const u64 *> ptrs(NG, nullptr);
-    std::vector<unsigned> gal(NG, 1u), ginv(NG, 1u);
+    if (X <= 0) {
+        giants_valid = true;
+        giants_B = B;
+        giants_G = G;
+        return;
+    }
+    std::vector<const u64 *> ptrs(X, nullptr);
+    std::vector<unsigned> gal(X, 1u), ginv(X, 1u);
     for (int g = 1; g < NG; g++) {
         auto it = rot_keys.find(g * B);
         if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(g * B) + " not loaded");
-        ptrs[g] = it->second.d;
-        gal[g] = (unsigned)galois_elt(g * B);
+        const unsigned ge = (unsigned)galois_elt(g * B);
         u64 x = 1;
-        for (int k = 0; k < 6; k++) x = x * (2 - (u64)gal[g] * x);
-        ginv[g] = (unsigned)(x & (2ull * N - 1));
+        for (int k = 0; k < 6; k++) x = x * (2 - (u64)ge * x);
+        for (int m = 0; m < G; m++) {  // giant-major batch: the G blocks of one giant step share its key (adjacent in the launch)
+            ptrs[(size_t)(g - 1) * G + m] = it->second.d;
+            gal[(size_t)(g - 1) * G + m] = ge;
+            ginv[(size_t)(g - 1) * G + m] = (unsigned)(x & (2ull * N - 1));
+        }
     }
-    if (!d_giant_keys) {
-        HIP_CHECK(hipMalloc((void **)&d_giant_keys, sizeof(u64 *) * NG));
-        HIP_CHECK(hipMalloc((void **)&d_giant_gal, sizeof(unsigned) * NG));
-        HIP_CHECK(hipMalloc((void **)&d_giant_ginv, sizeof(unsigned) * NG));
-    }
+    HIP_CHECK(hipMalloc((void **)&d_giant_keys, sizeof(u64 *) * X));
+    HIP_CHECK(hipMalloc((void **)&d_giant_gal, sizeof(unsigned) * X));
+    HIP_CHECK(hipMalloc((void **)&d_giant_ginv, sizeof(unsigned) * X));
     sync_all();
-    HIP_CHECK(hipMemcpy((void *)d_giant_keys, ptrs.data(), sizeof(u64 *) * NG, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_giant_gal, gal.data(), sizeof(unsigned) * NG, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_giant_ginv, ginv.data(), sizeof(unsigned) * NG, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((void *)d_giant_keys, ptrs.data(), sizeof(u64 *) * X, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_giant_gal, gal.data(), sizeof(unsigned) * X, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_giant_ginv, ginv.data(), sizeof(unsigned) * X, hipMemcpyHostToDevice));
     giants_valid = true;
     giants_B = B;
+    giants_G = G;
 }
 Ct Context::similarity_bsgs_sum(const Ct &qc) {
     if (!d_db || db_cts == 0 || db_kind != 6) throw StateError("hydia: no database resident (pre-rotated diagonal packing)");
@@ -843,34 +851,32 @@ Ct Context::similarity_bsgs_sum(const Ct &qc) {
     const int dim = prm.dim, B = db_babies, NG = (dim + B - 1) / B;
     if (B < 1 || dim % B) throw StateError("hydia: the resident database carries no valid baby count");
     const int G = (int)(db_cts / dim), nl = nQ, nE = nl + nP, nd = (nl + alpha - 1) / alpha;
-    build_giants();
+    build_giants(G);
     // babies: rotations 0 .. B-1 of the query (loop A on B - 1 keys)
     Ct rot(this, B, 2, nl, qc.scale);
     rotate_query_range(qc, 0, B, rot.d);
-    // inner sums: ciphertext t = (block*NG + g)*B + b is "diagonal b of block block*NG + g"
+    // inner sums: ciphertext t = (block*NG + g)*B + b is "diagonal b of block block*NG + g"; the accumulators come out giant-major
+    // (slot g*G + block), so every later step is ONE batch over all database blocks
     Ct acc(this, G * NG, 3, nl, qc.scale * delta);
     timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G * NG, B, nl, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G * NG, B, nl, tensor_bpp, tensor_nw, db_packed ? 1 : 0, NG);
     timer_end("hydia_tensor");
-    relinearize(acc);  // [G*NG][2][nl]
-    // giant steps: per block the partial sums g >= 1 go through ONE batched key switch with rotation key B g each (the
-    // automorphism rides in the ModDown epilogue), land next to the unrotated g = 0 sum and are added up
+    relinearize(acc);  // [NG*G][2][nl]
+    // giant steps: the partial sums g >= 1 of ALL blocks go through one batched key switch, rotation key B g for slot (g, block)
+    // (the automorphism rides in the ModDown epilogue); then out[block] = sum over g of slot (g, block)
     Ct out(this, G, 2, nl, acc.scale);
-    Ct part(this, NG, 2, nl, acc.scale);
-    u64 *dig = NG > 1 ? pool.get((size_t)(NG - 1) * nd * nE * N * sizeof(u64)) : nullptr;
-    const size_t ce = acc.ct_elems();
-    for (int m = 0; m < G; m++) {
-        const u64 *base = acc.d + (size_t)m * NG * ce;
-        HIP_CHECK(hipMemcpyAsync(part.d, base, ce * sizeof(u64), hipMemcpyDeviceToDevice, stream));
-        if (NG > 1) {
-            const u64 *c = base + ce;  // partial sums g = 1 ..
-            modup_digits(c + acc.poly_elems(), ce, NG - 1, nl, dig);
-            ks_apply(dig, (size_t)nd * nE * N, NG - 1, nl, d_giant_keys + 1, 0, c, ce, acc.poly_elems(), 1, d_giant_gal + 1,
-                     d_giant_ginv + 1, 0, false, part.d + ce);
-        }
-        hk::batch_sum(stream, d_mod, N, part.d, out.d + (size_t)m * ce, NG, 2, nl);
+    if (NG > 1) {
+        const int X = (NG - 1) * G;
+        const size_t ce = acc.ct_elems();
+        Ct rotd(this, X, 2, nl, acc.scale);
+        u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
+        const u64 *c = acc.d + (size_t)G * ce;
+        modup_digits(c + acc.poly_elems(), ce, X, nl, dig);
+        ks_apply(dig, (size_t)nd * nE * N, X, nl, d_giant_keys, 0, c, ce, acc.poly_elems(), 1, d_giant_gal, d_giant_ginv, 0, false, rotd.d);
+        pool.put(dig);
+        HIP_CHECK(hipMemcpyAsync(acc.d + (size_t)G * ce, rotd.d, (size_t)X * ce * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     }
-    if (dig) pool.put(dig);
+    hk::batch_sum(stream, d_mod, N, acc.d, out.d, NG, 2, nl, G, G);
     return out;
 }
 

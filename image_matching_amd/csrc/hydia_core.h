@@ -190,8 +190,8 @@ struct Context : HostParams {
     const u64 **d_giant_keys = nullptr;  // device arrays over g = 0 .. dim/B - 1: key, Galois element and inverse of rotation B g
     unsigned *d_giant_gal = nullptr, *d_giant_ginv = nullptr;
     bool giants_valid = false;
-    int giants_B = 0;
-    void build_giants();
+    int giants_B = 0, giants_G = 0;  // the tables hold one entry per (giant step g >= 1, database block): x = (g - 1) * G + block
+    void build_giants(int G);
     bool db_packed = true;
     DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }
     void db_resize(size_t n_vectors, size_t cts);         // (re)allocates the resident layout for `cts` ciphertexts

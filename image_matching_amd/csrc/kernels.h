@@ -227,7 +227,8 @@ void lincomb(hipStream_t st, const ModC *mod, int N, const LinComb &lc, u64 *o, 
 // o[p][j] = sum_x in[x][p][j] mod q_j: EvalAdd chain over a batch (HERS sums its 512 per-dimension products); o compact
 // out[k][x][p][j][c] = sum_t tab[k][t][j] * src_t[x][p][j][c] (+ c0[k][j] on polynomial 0)
 void lincomb_multi(hipStream_t st, const ModC *mod, int N, const LinCombMulti &lc, u64 *o, int X, int npoly, int nl);
-void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl);
+// stride / nout: output m (m < nout) = sum over x of ciphertext m + x * stride (the giant-major partial sums of the BSGS mat-vec)
+void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl, int stride = 1, int nout = 1);
 // (a0 b0, a0 b1 + a1 b0, a1 b1) for X ciphertext pairs at nl limbs; o: [X][3][nl][N]
 void tensor(hipStream_t st, const ModC *mod, int N, const u64 *a, const u64 *b, u64 *o, int X, int nl, int a_ls, int b_ls,
             const u64 *c = nullptr, int c_ls = 0, const ScaleSel *kap = nullptr);
@@ -294,8 +295,10 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
                      const ScaleSel &qlinv, int in_ls);
 
 // ---- loop B of the HyDia sender: acc[g][3][nl][N] = sum_i rot[i] (x) db[g][i], fully reduced
+// ng > 0: the G "blocks" are (database block, giant step) pairs, block-major in the database; accumulator (block, g) is written to
+// slot g * (G / ng) + block (giant-major), so that one giant step's partial sums over all database blocks are one contiguous batch
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
-                             int dim, int nl, int bpp, int nw, int packed);
+                             int dim, int nl, int bpp, int nw, int packed, int ng = 0);
 const char *hydia_tensor_kernel_name();
 
 // ---- misc

@@ -212,22 +212,23 @@ __global__ __launch_bounds__(256) void k_lincomb_multi(const ModC *__restrict__ 
     }
 }
 // grid (N/512, nl, npoly): serial sum over the batch with 128-bit accumulators (X * 2^60 fits)
+// output m (grid.z = npoly * nout) = sum over x of ciphertext m + x * stride of `in` (stride 1, nout 1: a plain batch sum)
 __global__ __launch_bounds__(256) void k_batch_sum(const ModC *__restrict__ mod, int N, const u64 *__restrict__ in,
-                                                   u64 *__restrict__ o, int X, int npoly, int nl) {
-    const int j = blockIdx.y, p = blockIdx.z;
+                                                   u64 *__restrict__ o, int X, int npoly, int nl, int stride) {
+    const int j = blockIdx.y, p = blockIdx.z % npoly, m = blockIdx.z / npoly;
     const ModC M = mod[j];
     const size_t i = ((size_t)p * nl + j) * N + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
-    const size_t xs = (size_t)npoly * nl * N;
+    const size_t cs = (size_t)npoly * nl * N, xs = cs * (size_t)stride;
     u128 ax = 0, ay = 0;
     for (int x = 0; x < X; x++) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(in + (size_t)x * xs + i);
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(in + (size_t)m * cs + (size_t)x * xs + i);
         ax += v.x;
         ay += v.y;
     }
     ulonglong2 r;
     r.x = reduce128(ax, M);
     r.y = reduce128(ay, M);
-    *reinterpret_cast<ulonglong2 *>(o + i) = r;
+    *reinterpret_cast<ulonglong2 *>(o + (size_t)m * cs + i) = r;
 }
 __global__ __launch_bounds__(256) void k_add_scalar(const ModC *__restrict__ mod, int N, u64 *__restrict__ a,
                                                     size_t outer, LimbSel sel, ScaleSel c) {
@@ -548,7 +549,7 @@ HD size_t db_limb_offset(const DbLayout &L, int N, int j) {
 template <int BPP, int NW, bool NT, bool PK>
 __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
                                                              const unsigned char *__restrict__ db, u64 *__restrict__ acc,
-                                                             int dim, int nl, int Gq, int xcd_map, DbLayout L, int j0) {
+                                                             int dim, int nl, int Gq, int xcd_map, DbLayout L, int j0, int ng, int nblk) {
     const int j = blockIdx.y + j0;
     // consecutive workgroup ids are dealt round-robin over the 8 XCDs: give every XCD its own tiles and let the Gq block
     // groups of one tile follow each other ON THAT XCD, so they find the tile's rot lines in its L2
@@ -603,7 +604,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restr
         r2.x = reduce128(d2x[u], M); r2.y = reduce128(d2y[u], M);
         r1.x = submod(submod(reduce128(dkx[u], M), r0.x, M.q), r2.x, M.q);
         r1.y = submod(submod(reduce128(dky[u], M), r0.y, M.q), r2.y, M.q);
-        u64 *o = acc + ((size_t)(g0 + u) * 3 * nl + j) * N + c;
+        // ng > 0 (baby-step / giant-step split): accumulator of "block" gi = (database block, giant g) goes to slot g * blocks + block,
+        // so that the partial sums of one giant step over all database blocks are one contiguous batch
+        const int gi = g0 + u, go = ng > 0 ? (gi % ng) * nblk + gi / ng : gi;
+        u64 *o = acc + ((size_t)go * 3 * nl + j) * N + c;
         *reinterpret_cast<ulonglong2 *>(o) = r0;
         *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
         *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restr
 template <int KS, bool PK>
 __global__ __launch_bounds__(64 * KS) void k_hydia_tensor_sk(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
                                                              const unsigned char *__restrict__ db, u64 *__restrict__ acc, int dim,
-                                                             int nl, DbLayout L, int j0) {
+                                                             int nl, DbLayout L, int j0, int ng, int nblk) {
     __shared__ u64 part[KS][6][64];
     const int j = blockIdx.y + j0, tiles = N / 128;
     const int tile = blockIdx.x % tiles, g = blockIdx.x / tiles;
@@ -661,7 +665,8 @@ __global__ __launch_bounds__(64 * KS) void k_hydia_tensor_sk(const ModC *__restr
             for (int w = 1; w < KS; w++) t = addmod(t, part[w][k][lane], M.q);
             r[k] = t;
         }
-        u64 *o = acc + ((size_t)g * 3 * nl + j) * N + c;
+        const int go = ng > 0 ? (g % ng) * nblk + g / ng : g;  // giant-major order (see k_hydia_tensor)
+        u64 *o = acc + ((size_t)go * 3 * nl + j) * N + c;
         *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2(r[0], r[1]);
         *reinterpret_cast<ulonglong2 *>(o + ps) = make_ulonglong2(submod(submod(r[2], r[0], M.q), r[4], M.q), submod(submod(r[3], r[1], M.q), r[5], M.q));
         *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = make_ulonglong2(r[4], r[5]);
@@ -796,9 +801,9 @@ void lincomb_multi(hipStream_t st, const ModC *mod, int N, const LinCombMulti &l
     ledger_add("k_lincomb_multi", (lc.nterms + (double)lc.K) * X * npoly * nl * LP_BYTES(N));
     hipLaunchKernelGGL(k_lincomb_multi, dim3(N / 512, nl, X * npoly), dim3(256), 0, st, mod, N, lc, o, X * npoly, npoly, nl);
 }
-void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl) {
-    ledger_add("k_batch_sum", (X + 1.0) * npoly * nl * LP_BYTES(N));
-    hipLaunchKernelGGL(k_batch_sum, dim3(N / 512, nl, npoly), dim3(256), 0, st, mod, N, in, o, X, npoly, nl);
+void batch_sum(hipStream_t st, const ModC *mod, int N, const u64 *in, u64 *o, int X, int npoly, int nl, int stride, int nout) {
+    ledger_add("k_batch_sum", (X + 1.0) * nout * npoly * nl * LP_BYTES(N));
+    hipLaunchKernelGGL(k_batch_sum, dim3(N / 512, nl, npoly * nout), dim3(256), 0, st, mod, N, in, o, X, npoly, nl, stride);
 }
 void add_scalar(hipStream_t st, const ModC *mod, int N, u64 *a, size_t outer, int X, const LimbSel &sel,
                 const ScaleSel &c) {
@@ -894,7 +899,8 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
 }
 template <int BPP, int NW>
 static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G, int dim,
-                          int nl, const DbLayout &L) {
+                          int nl, const DbLayout &L, int ng) {
+    const int nblk = ng > 0 ? G / ng : 0;
     const int Gq = G / (BPP * NW);
     const int xm = (N / 128) % 8 == 0 ? 1 : 0;  // XCD-aware tile -> workgroup map
     const unsigned char *dbb = (const unsigned char *)db;
@@ -915,23 +921,23 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
     }
     if (L.packed) {  // limb 0 (8-byte residues) and limbs 1.. (6-byte residues) as two launches: no shared register budget
         if (G <= 2)  // few blocks: 256 x G one-wave workgroups cannot hide the latency of 512 dependent steps -> split the diagonals
-            hipLaunchKernelGGL((k_hydia_tensor_sk<16, false>), dim3((N / 128) * G, 1), dim3(64 * 16), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0);
+            hipLaunchKernelGGL((k_hydia_tensor_sk<16, false>), dim3((N / 128) * G, 1), dim3(64 * 16), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0, ng, nblk);
         else if (G <= 8)
-            hipLaunchKernelGGL((k_hydia_tensor_sk<4, false>), dim3((N / 128) * G, 1), dim3(64 * 4), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0);
+            hipLaunchKernelGGL((k_hydia_tensor_sk<4, false>), dim3((N / 128) * G, 1), dim3(64 * 4), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0, ng, nblk);
         else
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
-                               Gq, xm, L, 0);
+                               Gq, xm, L, 0, ng, nblk);
         if (nl > 1)
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, true>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc,
-                               dim, nl, Gq, xm, L, 1);
+                               dim, nl, Gq, xm, L, 1, ng, nblk);
     } else {
         hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, nl), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
-                           Gq, xm, L, 0);
+                           Gq, xm, L, 0, ng, nblk);
     }
 }
 // bpp = database blocks per wave, nw = max waves per workgroup (0: up to 16); both must divide G
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
-                             int dim, int nl, int bpp, int nw, int packed) {
+                             int dim, int nl, int bpp, int nw, int packed, int ng) {
     DbLayout L = db_layout(N, nl, packed);
     int B = (bpp >= 4 && G % 4 == 0) ? 4 : (bpp >= 2 && G % 2 == 0) ? 2 : 1;
     const int rest = G / B;
@@ -942,7 +948,7 @@ void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *
             break;
         }
 #define HY_TENSOR_CASE(b, w) \
-    if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl, L);
+    if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl, L, ng);
     HY_TENSOR_CASE(4, 16) HY_TENSOR_CASE(4, 8) HY_TENSOR_CASE(4, 4) HY_TENSOR_CASE(4, 2) HY_TENSOR_CASE(4, 1)
     HY_TENSOR_CASE(2, 16) HY_TENSOR_CASE(2, 8) HY_TENSOR_CASE(2, 4) HY_TENSOR_CASE(2, 2) HY_TENSOR_CASE(2, 1)
     HY_TENSOR_CASE(1, 16) HY_TENSOR_CASE(1, 8) HY_TENSOR_CASE(1, 4) HY_TENSOR_CASE(1, 2) HY_TENSOR_CASE(1, 1)
