@@ -290,7 +290,11 @@ def main():
     # loop A across ranks (untimed set-up): both forms give the same ciphertexts; which is faster depends on what the node's xGMI
     # all-gather of the 3 GiB of rotated queries costs against recomputing them — measured here, on this node, then fixed
     loop_a = None
-    if multi and world > 1:
+    if multi and world > 1 and getattr(sender, "bsgs", False):
+        # few blocks per GPU: the database is enrolled for a short loop A (B - 1 hoisted rotations, giant steps per block): nothing to share out
+        loop_a = {"mode": "local", "why": "baby-step / giant-step split with %d babies: every rank computes its own %d rotations" % (cc.db_babies() or cc.auto_babies(max(G_local, 1)), (cc.db_babies() or cc.auto_babies(max(G_local, 1))) - 1)}
+        sender.rotation_split = False
+    elif multi and world > 1:
         loop_a = {"mode": args.loop_a}
         if args.loop_a == "auto":
             trial = {}

@@ -284,7 +284,7 @@ class DistDiagonalSender:
         return cc.import_ct(full.numpy().view(np.uint64).reshape(dim, 2, cc.nQ, cc.N), scale)
 
     def _local(self, fn_name, q):
-        if self.rotation_split:
+        if self.rotation_split and not self.bsgs and len(self.active) > 1:
             rot = self._gathered_rotations(q)
             return getattr(self.local, fn_name + "Rotated")(rot) if self.local is not None else None
         return getattr(self.local, fn_name)(q) if self.local is not None else None

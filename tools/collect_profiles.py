@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Copy the outputs of tools/gpu_r2_deliver.sh from gpurun_out/ into profiles/r02/ under a version tag and refresh
+"""Copy the outputs of tools/gpu_r3_deliver.sh from gpurun_out/ into profiles/<round>/ under a version tag and refresh
 profiles/tensor_traffic.json from the two PMC passes (tagged with the kernel source hash bench.py checks).
-Usage: collect_profiles.py v1"""
+Usage: collect_profiles.py v1 [round directory, default r03]"""
 import csv
 import json
 import os
@@ -11,7 +11,8 @@ import sys
 
 tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", "r02")
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", ROUND)
 os.makedirs(P, exist_ok=True)
 sys.path.insert(0, R)
 from bench import kernel_sha  # noqa: E402
@@ -28,6 +29,12 @@ cp("bench_final.json", "bench_2p20_%s.json" % tag)
 for l in (10, 14, 17):
     cp("bench_2p%d.json" % l, "bench_2p%d_%s.json" % (l, tag))
 cp("bench_kernel_stats.csv", "bench_2p20_kernel_stats_%s.csv" % tag)
+cp("kernel_rooflines_q14_hoisted.txt", "kernel_rooflines_q14_hoisted_%s.txt" % tag)
+cp("kernel_rooflines_rot.txt", "kernel_rooflines_loop_a_%s.txt" % tag)
+cp("pmc_sq_rot_summary.txt", "sq_counters_loop_a_%s.txt" % tag)
+cp("scaling_components_20.json", "scaling_components_2p20_%s.json" % tag)
+cp("scaling_components_17.json", "scaling_components_2p17_%s.json" % tag)
+cp("smoke.log", "smoke_%s.log" % tag)
 for l in (20, 14, 10):
     cp("kernel_rooflines_q%d.txt" % l, "kernel_rooflines_q%d_%s.txt" % (l, tag))
     cp("kernel_stats_q%d.csv" % l, "indexscenario_2p%d_queryonly_kernel_stats_%s.csv" % (l, tag))
@@ -61,7 +68,7 @@ out = {
     "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     "kernel_sha": kernel_sha(), "commit": head,
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (r02 %s)" % tag,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (%s %s)" % (ROUND, tag),
 }
 json.dump(out, open(os.path.join(R, "profiles", "tensor_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
