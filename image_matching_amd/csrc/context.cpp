@@ -279,12 +279,6 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
     for (int k = 1; k < nlanes; k++) {
         hipStream_t st;
-        if (getenv("HYDIA_LANE_PRIO")) {
-            int lo = 0, hi = 0;
-            HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            fprintf(stderr, "lane priority range %d..%d\n", lo, hi);
-            HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
-        } else
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         lane_stream.push_back(st);
     }
@@ -372,7 +366,6 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
             if (!((tabs.fp_mask >> m) & 1u) && mod[m].q < (1ull << 60) && (1ull << 60) - mod[m].q < (1ull << 24)) tabs.pm_mask |= 1u << m;
     if (const char *e = getenv("HYDIA_TENSOR_BPP")) tensor_bpp = atoi(e);
     if (const char *e = getenv("HYDIA_TENSOR_NW")) tensor_nw = atoi(e);
-    if (const char *e = getenv("HYDIA_PIPE")) pipe_chunks = std::max(0, atoi(e));
     merge_rescale = getenv("HYDIA_NO_MERGE_RESCALE") == nullptr;
     fuse_ip = getenv("HYDIA_NO_FUSE_IP") == nullptr;
     fork_products = getenv("HYDIA_NO_FORK") == nullptr;
@@ -419,7 +412,6 @@ Context::~Context() {
                     (void *)d_rotgalois, (void *)d_rotginv, (void *)d_sk, (void *)d_pk, (void *)d_db, (void *)d_rot_group, (void *)d_ksi})
         if (p) (void)hipFree(p);
     for (auto e : lane_ev) (void)hipEventDestroy(e);
-    for (auto e : pipe_ev) (void)hipEventDestroy(e);
     for (auto e : par_ev)
         if (e) (void)hipEventDestroy(e);
     for (size_t k = 1; k < lane_stream.size(); k++) (void)hipStreamDestroy(lane_stream[k]);

@@ -1239,93 +1239,12 @@ Ct Context::similarity_rot(const Ct &rot) {
     relin_rescale(acc);
     return acc;
 }
-// Chunks of blocks the pipelined indexScenario cuts loop B into (1 = no pipeline).  Every chunk re-reads the rotated queries
-// (3 GiB next to 2.3 GiB of database per block), so the chunks stay large.
-int Context::pipe_chunks_for(int G) const {
-    if (nlanes < 2 || pipe_chunks == 1 || G < 16) return 1;
-    if (pipe_chunks > 1) return std::min(pipe_chunks, G / 8);
-    return G >= 32 ? 4 : 2;
-}
-// indexScenario over MANY resident blocks, hoisted form: loop B runs in chunks of blocks on the main stream and the tail of a
-// chunk (relinearise, rescale, comparator) follows on a side lane as soon as that chunk's accumulators exist.  Loop B is
-// HBM-bound with the vector units half idle, the tail is bound by the vector units at a quarter of the HBM rate: run side by
-// side each fills the other's idle resource.  Same arithmetic per ciphertext as the one-launch form (exact modular sums).
-Ct Context::index_pipelined(const Ct &rot, double dlt, int sign_depth) {
-    if (!d_db || db_cts == 0 || db_kind != 5) throw StateError("hydia: no database resident (diagonal packing)");
-    const int dim = prm.dim;
-    if (rot.X != dim || rot.npoly != 2 || rot.nl != nQ || !rot.compact())
-        throw StateError("hydia: rotations must be vector_dim fresh 2-component ciphertexts");
-    const int G = (int)(db_cts / dim), TL = nlanes - 1;
-    const int want = pipe_chunks_for(G), step = (((G + want - 1) / want) + 7) & ~7;
-    std::vector<int> cut{0};
-    while (cut.back() < G) cut.push_back(std::min(G, cut.back() + step));
-    const int C = (int)cut.size() - 1;
-    // events: [0] main stream at entry, [1] result buffer allocated, [2 .. 2+TL) lane finished, then one per chunk
-    while ((int)pipe_ev.size() < 2 + TL + C) {
-        hipEvent_t e;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        pipe_ev.push_back(e);
-    }
-    std::vector<hipEvent_t> &ev = pipe_ev;
-    Ct acc(this, G, 3, nQ, rot.scale * delta);
-    const DbLayout lay = hk::db_layout(N, nQ, db_packed ? 1 : 0);
-    struct LaneGuard {
-        Context *c;
-        ~LaneGuard() {
-            c->set_lane(0);
-            c->side_lane_free = true;
-            if (std::uncaught_exceptions() > 0)
-                for (auto st : c->lane_stream) (void)hipStreamSynchronize(st);
-        }
-    } guard{this};
-    side_lane_free = false;
-    HIP_CHECK(hipEventRecord(ev[0], stream));  // blocks on the side lanes' free lists were released before this point
-    for (int l = 1; l <= TL; l++) HIP_CHECK(hipStreamWaitEvent(lane_stream[l], ev[0], 0));
-    std::vector<Ct> res(C);
-    Ct out;
-    for (int c = 0; c < C; c++) {
-        const int g0 = cut[c], Gc = cut[c + 1] - cut[c];
-        set_lane(0);
-        timer_begin("hydia_tensor");
-        hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, (const unsigned char *)d_db + (size_t)g0 * dim * lay.ct_bytes,
-                                    acc.d + (size_t)g0 * acc.ct_elems(), Gc, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
-        timer_end("hydia_tensor");
-        HIP_CHECK(hipEventRecord(ev[2 + TL + c], stream));
-        const int lane = 1 + c % TL;
-        set_lane(lane);
-        HIP_CHECK(hipStreamWaitEvent(stream, ev[2 + TL + c], 0));
-        Ct part = acc.alias(acc.nl);
-        part.X = Gc;
-        part.d = acc.d + (size_t)g0 * acc.ct_elems();
-        relin_rescale(part);
-        res[c] = chebyshev_compare(part, dlt, sign_depth);
-        if (c == 0) {
-            out = Ct(this, G, res[0].npoly, res[0].nl, res[0].scale);  // lane 1's memory: the other lanes write it after ev[1]
-            HIP_CHECK(hipEventRecord(ev[1], stream));
-        } else if (lane != 1) {
-            HIP_CHECK(hipStreamWaitEvent(stream, ev[1], 0));
-        }
-        Ct rk = res[c].compact() ? res[c].alias(res[c].nl) : clone(res[c]);
-        HIP_CHECK(hipMemcpyAsync(out.d + (size_t)g0 * out.ct_elems(), rk.d, rk.bytes(), hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipEventRecord(ev[2 + lane - 1], stream));
-    }
-    set_lane(0);
-    for (int l = 1; l <= std::min(TL, C); l++) HIP_CHECK(hipStreamWaitEvent(stream, ev[2 + l - 1], 0));
-    res.clear();
-    return out;
-}
 Ct Context::index_scenario_rot(const Ct &rot) {
-    if (db_cts && pipe_chunks_for((int)(db_cts / prm.dim)) > 1) return index_pipelined(rot, 0.44, 10);
     Ct acc = similarity_accumulate_rot(rot);
     return relin_compare_lanes(acc, 0.44, 10);
 }
 // indexScenario (sender_diag.cpp:52-63): loop A, loop B, then the per-block tails on the comparator lanes
 Ct Context::index_scenario(const Ct &qc) {
-    if (db_kind == 5 && db_cts && pipe_chunks_for((int)(db_cts / prm.dim)) > 1) {
-        if (qc.nl != nQ) throw StateError("hydia: query must be a fresh (level 0) ciphertext");
-        Ct rot = rotate_query(qc);
-        return index_pipelined(rot, 0.44 /* MATCH_THRESHOLD, include/config.h:9 */, 10 /* COMP_DEPTH, :14 */);
-    }
     Ct acc = db_kind == 6 ? similarity_bsgs_sum(qc) : similarity_accumulate(qc);  // 2 components (relinearised) : 3
     return relin_compare_lanes(acc, 0.44 /* MATCH_THRESHOLD, include/config.h:9 */, 10 /* COMP_DEPTH, :14 */);
 }

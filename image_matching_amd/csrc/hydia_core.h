@@ -280,10 +280,6 @@ struct Context : HostParams {
     Ct mult_norelin(const Ct &a, const Ct &b);
     Ct similarity_accumulate(const Ct &qc);
     Ct relin_compare_lanes(Ct &acc, double delta, int sign_depth);
-    Ct index_pipelined(const Ct &rot, double delta, int sign_depth);
-    int pipe_chunks = 0;            // loop B / tail pipeline of indexScenario: chunks of blocks (HYDIA_PIPE; 0 = rule, 1 = off)
-    int pipe_chunks_for(int G) const;
-    std::vector<hipEvent_t> pipe_ev;
     Ct mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c);
     Ct mult(const Ct &a, const Ct &b);  // align, tensor, relin, rescale
     Ct rotate(const Ct &a, int rot);    // X = any; full key switch
