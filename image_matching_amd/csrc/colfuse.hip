@@ -72,28 +72,25 @@ DEV void cf_inverse(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = ar.fin_inv(v[k], sc, scs);
 }
-// Conversion sums sum_s y_s f_s (four terms, y_s < 2^60, f_s < 2^60).  A 128-bit multiply-accumulate costs ~12 instructions as the
+// Conversion sums a = sum_s y_s f_s (four terms, y_s < 2^60, f_s < 2^60).  A 128-bit multiply-accumulate costs ~12 instructions as the
 // compiler builds it (four partial products, each followed by carry handling).  With both operands cut at 30 bits —
-// y = yh 2^30 + yl, f = fh 2^30 + fl — the three partial sums  sum yl fl,  sum (yl fh + yh fl),  sum yh fh  stay below 2^63, so they
-// are plain chains of v_mad_u64_u32 with no carries (16 for four terms), combined once: 28 instructions instead of 50.
-// Sources are kept in that split form (yl in the low dword, yh in the high one: the same two registers).
+// y = yh 2^30 + yl, f = fh 2^30 + fl — the three partial sums  ll = sum yl fl,  mid = sum (yl fh + yh fl),  hh = sum yh fh  stay below
+// 2^63, so they are plain chains of v_mad_u64_u32 with no carries (16 for four terms).  They leave as TWO words,
+// a = H 2^60 + L with L = ll + (mid mod 2^32) 2^30 < 2^63 and H = hh + 4 (mid >> 32), which is all either reduction needs.
+// Sources are kept in the split form (yl in the low dword, yh in the high one: the same two registers).
 DEV u64 cf_split30(u64 v) { return (v & 0x3FFFFFFFull) | ((v >> 30) << 32); }
 struct CfConst {
     unsigned lo[HY_CF_SRC], hi[HY_CF_SRC];
-    u64 full[HY_CF_SRC];
     DEV void set(int s, u64 f) {
         lo[s] = (unsigned)f & 0x3FFFFFFFu;
         hi[s] = (unsigned)(f >> 30);
-        full[s] = f;
     }
 };
-// The many-target kernel keeps 128 source registers alive across its target loop; the three partial sums per row of the split form
-// push it past its 256 registers (300-400 bytes of spills per lane, measured), so it stays with the plain 128-bit multiply-accumulate
-// on unsplit residues; the one-target kernel, which has registers to spare, takes the split form.
-DEV u128 cf_mac4_plain(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
-    return (u128)y0 * f.full[0] + (u128)y1 * f.full[1] + (u128)y2 * f.full[2] + (u128)y3 * f.full[3];
-}
-DEV u128 cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
+struct CfSum {
+    u64 L, H;
+    DEV u128 wide() const { return (u128)L + ((u128)H << 60); }
+};
+DEV CfSum cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
     const u64 y[HY_CF_SRC] = {y0, y1, y2, y3};
     u64 pll = 0, pmid = 0, phh = 0;
 #pragma unroll
@@ -104,7 +101,21 @@ DEV u128 cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
         pmid += (u64)yh * f.lo[s];
         phh += (u64)yh * f.hi[s];
     }
-    return (u128)pll + ((u128)pmid << 30) + ((u128)phh << 60);
+    CfSum r;
+    r.L = pll + ((pmid & 0xFFFFFFFFull) << 30);
+    r.H = phh + ((pmid >> 32) << 2);
+    return r;
+}
+// FP64 targets (q < 2^47, so f < 2^47 and H < 2^50): the transform is linear and exact on ANY representative below ~2 q in magnitude
+// (growth 0.75 q per stage, 15 stages, headroom 2^52), so the sum is folded in FP64 instead of being reduced to the canonical residue:
+// H (2^60 mod q) by one exact FP64 product with its quotient, the top dword of L times 2^32 with one quotient, the low dword as it is —
+// |operand| <= 1.4 q (H < 2^50: the quotient estimate is off by at most 3/8, so the first term stays below 0.875 q; the second below
+// 0.5 q; 1.9 q with the dropped limb's centred residue).  The canonical results after pass 2 are the same residues.
+DEV double cf_fold(const FpA &ar, const CfSum a, double c60) {
+    const double t1 = ar.mulmod2(FpA::u2d(a.H), c60);
+    const double h = (double)(unsigned)(a.L >> 32) * 4294967296.0;  // exact
+    const double t0 = __fma_rn(-rint(h * ar.qinv), ar.q, h);
+    return t1 + t0 + (double)(unsigned)a.L;
 }
 
 // split: leave the residues in the 30 + 30 bit form the conversion sums take (conversion sources; not the dropped limb)
@@ -165,8 +176,7 @@ DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[
                     unsigned neg, typename A::T (&v)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u128 a = cf_mac4_plain(y[0][k], y[1][k], y[2][k], y[3][k], f);
-        u64 r = reduce128k(a, M);
+        u64 r = reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f).wide(), M);
         if (MDR) {
             const u64 c = reduce64(um[k * 256], M);
             r = addmod(r, ((neg >> k) & 1u) ? negmod(c, M.q) : c, M.q);
@@ -174,23 +184,12 @@ DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[
         v[k] = ar.from_canon(r);
     }
 }
-// FP64 targets (q < 2^47): the transform is linear and exact on ANY representative below ~2 q in magnitude (growth 0.75 q per stage,
-// 15 stages, headroom 2^52), so the 128-bit sum a = a1 2^64 + a0h 2^32 + a0l (a1 < 2^46) is folded in FP64 instead of being reduced
-// to the canonical residue: a1 (2^64 mod q) and a0h 2^32 by exact FP64 products with one quotient each, a0l as it is — 16 instructions
-// instead of reduce128k + conversion (~32); |operand| <= 1.05 q (1.6 q with the dropped limb's centred residue).  The canonical
-// results after pass 2 are the same residues.
 template <bool MDR>
 DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
-                    unsigned neg, double (&v)[16]) {
-    const double c64 = FpA::u2d(0ull - M.r64 * M.q);  // 2^64 mod q
+                    unsigned neg, double c60, double (&v)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u128 a = cf_mac4_plain(y[0][k], y[1][k], y[2][k], y[3][k], f);
-        const u64 a0 = (u64)a;
-        const double t1 = ar.mulmod2(FpA::u2d((u64)(a >> 64)), c64);
-        const double h = (double)(unsigned)(a0 >> 32) * 4294967296.0;  // exact
-        const double t0 = __fma_rn(-rint(h * ar.qinv), ar.q, h);
-        double r = t1 + t0 + (double)(unsigned)a0;
+        double r = cf_fold(ar, cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f), c60);
         if (MDR) {
             const double c = FpA::u2d(um[k * 256]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
             r += ((neg >> k) & 1u) ? -c : c;
@@ -268,10 +267,10 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
 #pragma unroll
         for (int s = 2; s < HY_CF_SRC; s++) load_source(s);
     }
-    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, CF_NEXT_IMAGE(), g, col, cf.ssc[0], cf.ssc_sh[0], y[0], false);
-    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, CF_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], false);
-    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, CF_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], false);
-    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, CF_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], false);
+    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, CF_NEXT_IMAGE(), g, col, cf.ssc[0], cf.ssc_sh[0], y[0], true);
+    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, CF_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], true);
+    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, CF_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], true);
+    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, CF_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], true);
     // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
     unsigned neg = 0;
     if (MDR) {
@@ -282,8 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         for (int s = 0; s < HY_CF_SRC; s++) fl.set(s, s < cf.nk ? cf.fl[s] : 0);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const u128 a = cf_mac4_plain(y[0][k], y[1][k], y[2][k], y[3][k], fl);
-            const u64 yl = submod(umem[k * 256], reduce128k(a, Ml), Ml.q);  // own slot: no barrier needed
+            const u64 yl = submod(umem[k * 256], reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], fl).wide(), Ml), Ml.q);  // own slot: no barrier needed
             const bool ng = yl > half;
             umem[k * 256] = ng ? Ml.q - yl : yl;
             neg |= (ng ? 1u : 0u) << k;
@@ -299,13 +297,19 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         if (t < 128) ltw[t] = tw[t];
         u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;  // cf_forward adds the lane's column
         u64 *lds = CF_NEXT_IMAGE();
+        // the sources are loop-invariant: without this the compiler hoists per-source subexpressions of the conversion out of the target
+        // loop and runs out of registers (an empty statement, no instruction)
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("" : "+v"(y[s][k]));
         CfConst f;
 #pragma unroll
         for (int s = 0; s < HY_CF_SRC; s++) f.set(s, s < cf.nk ? cf.f[s][tt] : 0);
         if (fp) {
             const FpA ar(M);
             double v[16];
-            cf_convert<MDR>(ar, M, f, y, umem, neg, v);
+            cf_convert<MDR>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v);
             cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
         } else if ((T.pm_mask >> m) & 1u) {
             const IntP ar(M);
@@ -356,33 +360,29 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
     u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;
     // one row at a time: the (up to five) operands of row g + 8k are loaded where they are used; a holds sum_s y_s f_s, the dropped
     // limb's centred residue (MDR) is formed from the same operands
-    auto convert_row = [&](int k, u128 &a, u64 &mag, bool &ng) {
+    auto convert_row = [&](int k, CfSum &a, u64 &mag, bool &ng) {
         const size_t off = (size_t)(g + 8 * k) * 256;
         const u64 y0 = cf_split30(sp[0][off]), y1 = cf_split30(sp[1][off]), y2 = cf_split30(sp[2][off]), y3 = cf_split30(sp[3][off]);
         a = cf_mac4(y0, y1, y2, y3, f);
         mag = 0;
         ng = false;
         if (MDR) {
-            const u64 yl = submod(su[off], reduce128k(cf_mac4(y0, y1, y2, y3, fl), Ml), Ml.q);
+            const u64 yl = submod(su[off], reduce128k(cf_mac4(y0, y1, y2, y3, fl).wide(), Ml), Ml.q);
             ng = yl > (Ml.q >> 1);
             mag = ng ? Ml.q - yl : yl;
         }
     };
     if (fp) {
         const FpA ar(M);
-        const double c64 = FpA::u2d(0ull - M.r64 * M.q);  // 2^64 mod q (cf_convert's FP64 fold)
+        const double c60 = FpA::u2d(cf.t60[tt]);
         double v[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            u128 a;
+            CfSum a;
             u64 mag;
             bool ng;
             convert_row(k, a, mag, ng);
-            const u64 a0 = (u64)a;
-            const double t1 = ar.mulmod2(FpA::u2d((u64)(a >> 64)), c64);
-            const double h = (double)(unsigned)(a0 >> 32) * 4294967296.0;
-            const double t0 = __fma_rn(-rint(h * ar.qinv), ar.q, h);
-            double r = t1 + t0 + (double)(unsigned)a0;
+            double r = cf_fold(ar, a, c60);
             if (MDR) r += ng ? -FpA::u2d(mag) : FpA::u2d(mag);
             v[k] = r;
         }
@@ -391,11 +391,11 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
         u64 v[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            u128 a;
+            CfSum a;
             u64 mag;
             bool ng;
             convert_row(k, a, mag, ng);
-            u64 r = reduce128k(a, M);
+            u64 r = reduce128k(a.wide(), M);
             if (MDR) {
                 const u64 c = reduce64(mag, M);
                 r = addmod(r, ng ? negmod(c, M.q) : c, M.q);

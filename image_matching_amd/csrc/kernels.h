@@ -139,6 +139,7 @@ struct ColFuse {
     int tmod[HY_CF_TGT], trow[HY_CF_TGT];  // modulus id / row (in dst, per polynomial) of each target
     u64 f[HY_CF_SRC][HY_CF_TGT];           // conversion constants: target t = sum_k y_k f[k][t] mod q_tmod[t]
     u64 fl[HY_CF_SRC];                     // mdr: constants of the dropped limb, y_l = u - sum_k y_k fl[k] mod q_l
+    u64 t60[HY_CF_TGT];                    // 2^60 mod q_tmod[t] (the FP64 fold of the conversion sums; filled by cf_plan_store)
 };
 
 // resident database layout: ciphertext t at t*ct_bytes, polynomial p at + p*poly_bytes, limb 0 as N 8-byte residues, then
