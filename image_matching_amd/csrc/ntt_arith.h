@@ -64,9 +64,16 @@ struct IntP {
     DEV static T from_bits(u64 x) { return x; }
     DEV static u64 to_bits(T x) { return x; }
     DEV u64 fold(u64 x) const { return (x & ((1ull << 60) - 1)) + (u64)(unsigned)(x >> 60) * c; }
+    // Shoup product x w - floor(x w' / 2^64) q modulo 2^64, with -hi q = hi c - hi 2^60: one 32 x 32 multiply-add onto x w, and the high
+    // dword takes hi1 c - (hi0 << 28) — two multiplies instead of the three of a general 64 x 64 low product, and no borrow chain
+    DEV u64 shoup(u64 x, const TW W) const {
+        const u64 hi = __umul64hi(x, W.y);
+        const unsigned h0 = (unsigned)hi, h1 = (unsigned)(hi >> 32);
+        const u64 t = x * W.x + (u64)h0 * c;
+        return ((u64)((unsigned)(t >> 32) + h1 * c - (h0 << 28)) << 32) | (unsigned)t;  // the high dword alone: no 64-bit carry chain
+    }
     DEV void ct(T &a, T &b, const TW W) const {
-        const u64 hi = __umul64hi(b, W.y);
-        const u64 t = b * W.x - hi * q;
+        const u64 t = shoup(b, W);
         const u64 u = a;
         a = u + t;
         b = u - t + q2;
@@ -74,8 +81,7 @@ struct IntP {
     DEV void gs(T &a, T &b, const TW W) const {
         const u64 s = a + b;
         const u64 d = a - b + q8;
-        const u64 hi = __umul64hi(d, W.y);
-        b = d * W.x - hi * q;
+        b = shoup(d, W);
         a = s;
     }
     DEV void recentre(T &x) const { x = fold(x); }
