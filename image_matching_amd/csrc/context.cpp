@@ -177,7 +177,7 @@ HostParams::HostParams(const Params &p) : prm(p) {
     nQ = p.mult_depth + 1;
     alpha = (nQ + p.dnum - 1) / p.dnum;
     if (alpha > HY_MAX_DIGIT) throw std::runtime_error("hydia: digit too wide");
-    if (p.dim < 1 || (p.dim & (p.dim - 1)) || p.dim > slots) throw std::runtime_error("hydia: dim must be a power of two <= N/2");
+    if (p.dim < 2 || (p.dim & (p.dim - 1)) || p.dim > slots) throw std::runtime_error("hydia: dim must be a power of two, 2 <= dim <= N/2");
     delta = std::ldexp(1.0, p.scale_bits);
     const u64 M = 2ull * N;
 

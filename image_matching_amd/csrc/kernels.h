@@ -4,6 +4,7 @@
 // bit-reversed order (out[j] = a(psi^{2*bitrev(j)+1})) unless a comment says "coefficient form".  One wave reads 64
 // (or 128) consecutive coefficients of ONE limb, so the modulus constants are wave-uniform (SGPRs).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "devmath.h"
 
@@ -168,6 +169,30 @@ DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
     r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
     return r;
 }
+
+// the same in two steps — the raw load (what stays in flight) and the unpacking (where the value is used)
+template <bool PK>
+struct DbRaw {
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
+    typename std::conditional<PK, u3, ull2>::type w;
+    template <bool NT>
+    DEV void load(const unsigned char *p) {
+        typedef typename std::conditional<PK, u3, ull2>::type V;
+        w = NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(p)) : *reinterpret_cast<const V *>(p);
+    }
+    DEV ulonglong2 get() const {
+        ulonglong2 r;
+        if constexpr (PK) {
+            r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
+            r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
+        } else {
+            r.x = w.x;
+            r.y = w.y;
+        }
+        return r;
+    }
+};
 
 // packed key layout (loop A's rotation keys): per (digit, poly) one row set — modulus 0 as N 8-byte residues, the nQ-1 scaling
 // moduli (< 2^48) as N 6-byte residues each, then the nP special moduli as N 8-byte residues.  -17 % of the 12 GiB key stream.

@@ -202,26 +202,49 @@ struct P2Pre {
 };
 // mode 5: the accumulator value of 4 consecutive coefficients of limb j, key polynomial p, rotation x — formed here instead of
 // being read back: nd lazy 128-bit products per coefficient, one reduction
-DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+// The operands of one call: for every digit two pairs of digit residues and two pairs of key residues.  ALL of them are requested
+// before the first product (digits beyond nd re-read the last one and are not accumulated), through a branch-free sequence: at a join
+// the compiler would wait for every outstanding load, which is what made this kernel latency-bound (wait_any 0.64).
+constexpr int LA_MAXD = 3;  // digits fetched up front (dnum = 3); more digits take the serial tail loop
+template <bool SIX>
+struct LoopAOperands {
+    ulonglong2 v0[LA_MAXD], v1[LA_MAXD];
+    DbRaw<SIX> k0[LA_MAXD], k1[LA_MAXD];
+    DEV void fetch(const LoopAIp &la, const unsigned char *kp, size_t set_bytes, int jd, unsigned idx) {
+        constexpr int N = 32768;
+#pragma unroll
+        for (int d = 0; d < LA_MAXD; d++) {
+            const int dd = d < la.nd ? d : la.nd - 1;
+            const u64 *dg = la.dig + ((size_t)dd * la.dig_rows + jd) * N + idx;
+            v0[d] = *reinterpret_cast<const ulonglong2 *>(dg);
+            v1[d] = *reinterpret_cast<const ulonglong2 *>(dg + 2);
+            const unsigned char *kd = kp + (size_t)(2 * dd) * set_bytes;
+            k0[d].template load<false>(kd);
+            k1[d].template load<false>(kd + (SIX ? 12 : 16));
+        }
+    }
+};
+template <bool SIX>
+DEV void loop_a_ip_int(const LoopAIp &la, const ModC &M, const unsigned char *kp, size_t set_bytes, int jd, unsigned idx, ulonglong2 &o0,
+                       ulonglong2 &o1) {
     constexpr int N = 32768;
-    const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
-    const int j = la.key_row0 + slot, jd = la.dig_row0 + slot;
-    const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
-    const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
-    const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
+    LoopAOperands<SIX> op;
+    op.fetch(la, kp, set_bytes, jd, idx);
     u128 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int d = 0; d < la.nd; d++) {
+#pragma unroll
+    for (int d = 0; d < LA_MAXD; d++) {
+        const ulonglong2 k0 = op.k0[d].get(), k1 = op.k1[d].get();
+        const u64 on = d < la.nd ? ~0ull : 0ull;  // a mask, not a branch
+        a0 += (u128)(op.v0[d].x & on) * k0.x;
+        a1 += (u128)(op.v0[d].y & on) * k0.y;
+        a2 += (u128)(op.v1[d].x & on) * k1.x;
+        a3 += (u128)(op.v1[d].y & on) * k1.y;
+    }
+    for (int d = LA_MAXD; d < la.nd; d++) {
         const u64 *dg = la.dig + ((size_t)d * la.dig_rows + jd) * N + idx;
         const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(dg), v1 = *reinterpret_cast<const ulonglong2 *>(dg + 2);
         const unsigned char *kd = kp + (size_t)(2 * d) * set_bytes;
-        ulonglong2 k0, k1;
-        if (six) {
-            k0 = db_load2<true, false>(kd);
-            k1 = db_load2<true, false>(kd + 12);
-        } else {
-            k0 = db_load2<false, false>(kd);
-            k1 = db_load2<false, false>(kd + 16);
-        }
+        const ulonglong2 k0 = db_load2<SIX, false>(kd), k1 = db_load2<SIX, false>(kd + (SIX ? 12 : 16));
         a0 += (u128)v0.x * k0.x;
         a1 += (u128)v0.y * k0.y;
         a2 += (u128)v1.x * k1.x;
@@ -230,29 +253,27 @@ DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, in
     o0 = make_ulonglong2(reduce_lazy(a0, M, la.nd), reduce_lazy(a1, M, la.nd));
     o1 = make_ulonglong2(reduce_lazy(a2, M, la.nd), reduce_lazy(a3, M, la.nd));
 }
-// the same sum for a prime below 2^47 on the FP64 pipe: every product is reduced exactly (FpA::mulmod2, 6 full-rate operations
-// against the ~12 quarter-rate integer multiplies of a 128-bit product), the three remainders add exactly, one final reduction
-// gives the canonical residue — bit-identical to the integer sum
-DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+template <bool SIX>
+DEV void loop_a_ip_fp(const LoopAIp &la, const FpA &ar, const unsigned char *kp, size_t set_bytes, int jd, unsigned idx, ulonglong2 &o0,
+                      ulonglong2 &o1) {
     constexpr int N = 32768;
-    const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
-    const int j = la.key_row0 + slot, jd = la.dig_row0 + slot;
-    const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
-    const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
-    const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
+    LoopAOperands<SIX> op;
+    op.fetch(la, kp, set_bytes, jd, idx);
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int d = 0; d < la.nd; d++) {
+#pragma unroll
+    for (int d = 0; d < LA_MAXD; d++) {
+        const ulonglong2 k0 = op.k0[d].get(), k1 = op.k1[d].get();
+        const u64 on = d < la.nd ? ~0ull : 0ull;
+        a0 += ar.mulmod2(FpA::u2d(op.v0[d].x & on), FpA::u2d(k0.x));
+        a1 += ar.mulmod2(FpA::u2d(op.v0[d].y & on), FpA::u2d(k0.y));
+        a2 += ar.mulmod2(FpA::u2d(op.v1[d].x & on), FpA::u2d(k1.x));
+        a3 += ar.mulmod2(FpA::u2d(op.v1[d].y & on), FpA::u2d(k1.y));
+    }
+    for (int d = LA_MAXD; d < la.nd; d++) {
         const u64 *dg = la.dig + ((size_t)d * la.dig_rows + jd) * N + idx;
         const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(dg), v1 = *reinterpret_cast<const ulonglong2 *>(dg + 2);
         const unsigned char *kd = kp + (size_t)(2 * d) * set_bytes;
-        ulonglong2 k0, k1;
-        if (six) {
-            k0 = db_load2<true, false>(kd);
-            k1 = db_load2<true, false>(kd + 12);
-        } else {
-            k0 = db_load2<false, false>(kd);
-            k1 = db_load2<false, false>(kd + 16);
-        }
+        const ulonglong2 k0 = db_load2<SIX, false>(kd), k1 = db_load2<SIX, false>(kd + (SIX ? 12 : 16));
         a0 += ar.mulmod2(FpA::u2d(v0.x), FpA::u2d(k0.x));
         a1 += ar.mulmod2(FpA::u2d(v0.y), FpA::u2d(k0.y));
         a2 += ar.mulmod2(FpA::u2d(v1.x), FpA::u2d(k1.x));
@@ -260,6 +281,26 @@ DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p,
     }
     o0 = make_ulonglong2(ar.fin_fwd(a0), ar.fin_fwd(a1));
     o1 = make_ulonglong2(ar.fin_fwd(a2), ar.fin_fwd(a3));
+}
+DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    constexpr int N = 32768;
+    const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
+    const int j = la.key_row0 + slot, jd = la.dig_row0 + slot;
+    const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
+    const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
+    const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
+    if (six) loop_a_ip_int<true>(la, M, kp, set_bytes, jd, idx, o0, o1);
+    else loop_a_ip_int<false>(la, M, kp, set_bytes, jd, idx, o0, o1);
+}
+DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
+    constexpr int N = 32768;
+    const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
+    const int j = la.key_row0 + slot, jd = la.dig_row0 + slot;
+    const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
+    const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
+    const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
+    if (six) loop_a_ip_fp<true>(la, ar, kp, set_bytes, jd, idx, o0, o1);
+    else loop_a_ip_fp<false>(la, ar, kp, set_bytes, jd, idx, o0, o1);
 }
 DEV void loop_a_inner_product(const LoopAIp &la, const IntA &, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
@@ -684,7 +725,9 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 
 // grid (16 chunks of 2048, (X/NP)*sel.n)
 template <bool INV, int NP, int ST>
-__global__ __launch_bounds__(256) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
+// (loop A's fused inner product asks for three workgroups per CU: unbounded it takes 171 registers — two per CU, 6.24 ms per
+// rotateQuery; at 167 it keeps its twelve loads per call in flight with three, 5.95 ms; capped to 128 it spills, 6.13 ms)
+__global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : 1) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
                                                   size_t dso, LimbSel sel, int slot0, int nsl, NttStore stp) {
     constexpr int N = 32768;
     __shared__ u64 lds[NP][8 * 288];
