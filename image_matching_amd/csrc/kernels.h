@@ -4,7 +4,6 @@
 // bit-reversed order (out[j] = a(psi^{2*bitrev(j)+1})) unless a comment says "coefficient form".  One wave reads 64
 // (or 128) consecutive coefficients of ONE limb, so the modulus constants are wave-uniform (SGPRs).
 #pragma once
-#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "devmath.h"
 
@@ -170,26 +169,37 @@ DEV ulonglong2 db_load2(const unsigned char *p) {  // two consecutive residues
     return r;
 }
 
-// the same in two steps — the raw load (what stays in flight) and the unpacking (where the value is used)
+// the same in two steps — the raw load (what stays in flight) and the unpacking (where the value is used).  (Two explicit
+// specialisations: a typedef's alignment does not survive being a template argument, and the 12-byte loads are only 4-byte aligned.)
 template <bool PK>
-struct DbRaw {
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+struct DbRaw;
+template <>
+struct DbRaw<true> {
     typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
-    typename std::conditional<PK, u3, ull2>::type w;
+    u3 w;
     template <bool NT>
     DEV void load(const unsigned char *p) {
-        typedef typename std::conditional<PK, u3, ull2>::type V;
-        w = NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(p)) : *reinterpret_cast<const V *>(p);
+        w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(p)) : *reinterpret_cast<const u3 *>(p);
     }
     DEV ulonglong2 get() const {
         ulonglong2 r;
-        if constexpr (PK) {
-            r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
-            r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
-        } else {
-            r.x = w.x;
-            r.y = w.y;
-        }
+        r.x = (u64)w.x | ((u64)(w.y & 0xFFFFu) << 32);
+        r.y = (u64)(w.y >> 16) | ((u64)w.z << 16);
+        return r;
+    }
+};
+template <>
+struct DbRaw<false> {
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    ull2 w;
+    template <bool NT>
+    DEV void load(const unsigned char *p) {
+        w = NT ? __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(p)) : *reinterpret_cast<const ull2 *>(p);
+    }
+    DEV ulonglong2 get() const {
+        ulonglong2 r;
+        r.x = w.x;
+        r.y = w.y;
         return r;
     }
 };
