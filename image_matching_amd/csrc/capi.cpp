@@ -406,7 +406,7 @@ int hydia_db_alloc(hydia_ctx *ctx, size_t n_vectors) {
     API_BEGIN
     use_device(ctx);
     REQUIRE(ctx && n_vectors >= 1, "bad argument");
-    ctx->cx.db_resize(n_vectors, hydia_db_num_cts(ctx, n_vectors));
+    ctx->cx.db_resize(n_vectors, hydia_db_num_cts(ctx, n_vectors), ctx->cx.prm.dim);
     ctx->cx.db_kind = 5;
     ctx->cx.db_babies = ctx->cx.prm.dim;
     return HYDIA_OK;
@@ -455,7 +455,8 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     REQUIRE(ctx && n_vectors >= 1, "bad argument");
     Context &cx = ctx->cx;
     const size_t cts = hydia_db_num_cts(ctx, n_vectors);
-    cx.db_resize(n_vectors, cts);
+    const int babies = cx.babies_for((n_vectors + (size_t)cx.slots - 1) / (size_t)cx.slots);  // random residues: the cost model of the split auto picks
+    cx.db_resize(n_vectors, cts, babies);
     const size_t chunk = (size_t)cx.prm.dim, e = (size_t)2 * cx.nQ * cx.N;
     u64 *tmp = cx.pool.get(chunk * e * sizeof(u64));
     for (size_t t0 = 0; t0 < cts; t0 += chunk) {
@@ -465,7 +466,7 @@ int hydia_db_fill_random(hydia_ctx *ctx, size_t n_vectors, uint64_t seed) {
     }
     cx.sync();
     cx.pool.put(tmp);
-    cx.db_babies = cx.babies_for((n_vectors + (size_t)cx.slots - 1) / (size_t)cx.slots);  // random residues: the cost model of the split auto picks
+    cx.db_babies = babies;
     cx.db_kind = cx.db_babies < cx.prm.dim ? 6 : 5;
     return HYDIA_OK;
     API_END
@@ -480,7 +481,7 @@ int hydia_db_enroll_shard_ex(hydia_ctx *ctx, double *db, size_t n, const uint8_t
     const size_t G = (n + (size_t)cx.slots - 1) / (size_t)cx.slots;
     const int B = cx.babies_for(G, matvec);
     cx.db_kind = 0;
-    cx.db_resize(n, hydia_db_num_cts(ctx, n));
+    cx.db_resize(n, hydia_db_num_cts(ctx, n), B);
     client_enroll(cx, db, n, seed, first_block, B);
     cx.db_kind = B < cx.prm.dim ? 6 : 5;
     cx.db_babies = B;
@@ -506,7 +507,11 @@ int hydia_db_set_babies(hydia_ctx *ctx, int babies) {
     REQUIRE(ctx, "null argument");
     Context &cx = ctx->cx;
     if (!cx.d_db || cx.db_cts == 0 || cx.db_kind == 4) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
-    cx.db_babies = cx.babies_for(1, babies == cx.prm.dim ? 1 : babies);
+    const int B = cx.babies_for(1, babies == cx.prm.dim ? 1 : babies);
+    if (cx.db_lay.seq && B != cx.prm.dim)
+        return fail(HYDIA_ERR_STATE, "hydia: this database was laid out for the hoisted form (group-sequential); a baby-step / giant-step "
+                                     "database of this size has to be imported into a context created with HYDIA_DB_CT_MAJOR=1");
+    cx.db_babies = B;
     cx.db_kind = cx.db_babies < cx.prm.dim ? 6 : 5;
     return HYDIA_OK;
     API_END
@@ -521,7 +526,7 @@ int hydia_hers_db_enroll(hydia_ctx *ctx, double *db, size_t n, const uint8_t see
     REQUIRE(ctx && db && seed && n >= 1, "bad argument");
     Context &cx = ctx->cx;
     const size_t G = (n + cx.slots - 1) / cx.slots;  // enroller_hers.cpp:59-60
-    cx.db_resize(n, G * cx.prm.dim);
+    cx.db_resize(n, G * cx.prm.dim, -1);
     client_hers_enroll(cx, db, n, seed);
     cx.db_kind = 4;
     return HYDIA_OK;
@@ -559,6 +564,7 @@ int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_
     if (bytes) *bytes = ctx->cx.db_cts * ctx->cx.db_layout().ct_bytes;
     return HYDIA_OK;
 }
+int hydia_db_group(const hydia_ctx *ctx) { return ctx && ctx->cx.d_db ? ctx->cx.db_lay.seq : 0; }
 
 // ------------------------------------------------------------------ sender
 #define SENDER_CALL(expr)                                 \

@@ -379,6 +379,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     }
     rot_packed = getenv("HYDIA_KEYS_UNPACKED") == nullptr;
     db_packed = getenv("HYDIA_DB_UNPACKED") == nullptr;
+    db_seq_ok = getenv("HYDIA_DB_CT_MAJOR") == nullptr;
     for (int j = 1; j < nQ; j++)
         if (q[j] >> 48) db_packed = false;
     HIP_CHECK(hipMalloc((void **)&d_rotptrs, sizeof(u64 *) * (size_t)p.dim));
@@ -524,16 +525,21 @@ void Context::load_eval_key(int rot, const u64 *host) {
 }
 
 // ------------------------------------------------------------------ resident database
-void Context::db_resize(size_t n_vectors, size_t cts) {
-    const size_t bytes = cts * db_layout().ct_bytes;
+void Context::db_resize(size_t n_vectors, size_t cts, int form) {
+    const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);
+    const size_t bytes = cts * ctm.ct_bytes;
+    if (d_db) sync_all();  // the layout may change under a still asynchronous query
     if (d_db && db_cts != cts) {
-        sync_all();
         HIP_CHECK(hipFree(d_db));
         d_db = nullptr;
     }
     if (!d_db && bytes) HIP_CHECK(hipMalloc((void **)&d_db, bytes));
     db_cts = cts;
     db_vectors = n_vectors;
+    const size_t dim = (size_t)prm.dim;
+    db_lay = (db_seq_ok && db_packed && form == prm.dim && cts % dim == 0)
+                 ? hk::db_layout_seq(N, nQ, 1, prm.dim, (int)(cts / dim), tensor_bpp, tensor_nw)
+                 : ctm;
 }
 namespace {
 struct DbFileHeader {
@@ -554,6 +560,22 @@ struct PinnedBuf {
     explicit PinnedBuf(size_t n) { HIP_CHECK(hipHostMalloc(&p, n, hipHostMallocDefault)); }
     ~PinnedBuf() { (void)hipHostFree(p); }
 };
+// staging of the conversion between a group-sequential resident database and the ciphertext-major file: plain residues and a
+// ciphertext-major image of DB_CONV_CTS ciphertexts
+const size_t DB_CONV_CTS = 16;
+struct DbConv {
+    Context *cx;
+    u64 *plain = nullptr;
+    unsigned char *image = nullptr;
+    DbConv(Context *c, const DbLayout &ctm) : cx(c) {
+        plain = cx->pool.get(DB_CONV_CTS * 2 * cx->nQ * cx->N * sizeof(u64));
+        image = reinterpret_cast<unsigned char *>(cx->pool.get(DB_CONV_CTS * ctm.ct_bytes));
+    }
+    ~DbConv() {
+        cx->pool.put(plain);
+        cx->pool.put(reinterpret_cast<u64 *>(image));
+    }
+};
 }  // namespace
 void Context::db_save(const char *path) {
     if (!d_db || db_cts == 0) throw StateError("hydia: no database resident");
@@ -564,15 +586,30 @@ void Context::db_save(const char *path) {
     memcpy(h.magic, "HYDIADB1", 8);
     h.logN = (uint32_t)prm.logN; h.nQ = (uint32_t)nQ; h.dim = (uint32_t)prm.dim; h.packed = db_packed ? 1 : 0; h.kind = (uint32_t)db_kind;
     h.babies = (uint32_t)db_babies;
-    h.n_vectors = db_vectors; h.n_cts = db_cts; h.ct_bytes = db_layout().ct_bytes;
+    const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);  // the file is ALWAYS ciphertext-major
+    h.n_vectors = db_vectors; h.n_cts = db_cts; h.ct_bytes = ctm.ct_bytes;
     for (int j = 0; j < nQ; j++) h.moduli[j] = q[j];
     if (fwrite(&h, sizeof h, 1, fc.f) != 1) throw std::runtime_error("hydia: write failed (header)");
-    const size_t total = db_cts * db_layout().ct_bytes;
-    PinnedBuf buf(std::min(total, DB_IO_CHUNK));
-    for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
-        const size_t n = std::min(DB_IO_CHUNK, total - off);
-        HIP_CHECK(hipMemcpy(buf.p, d_db + off, n, hipMemcpyDeviceToHost));
-        if (fwrite(buf.p, 1, n, fc.f) != n) throw std::runtime_error("hydia: write failed (disk full?)");
+    const size_t total = db_cts * ctm.ct_bytes;
+    if (!db_lay.seq) {
+        PinnedBuf buf(std::min(total, DB_IO_CHUNK));
+        for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
+            const size_t n = std::min(DB_IO_CHUNK, total - off);
+            HIP_CHECK(hipMemcpy(buf.p, d_db + off, n, hipMemcpyDeviceToHost));
+            if (fwrite(buf.p, 1, n, fc.f) != n) throw std::runtime_error("hydia: write failed (disk full?)");
+        }
+        return;
+    }
+    // group-sequential resident layout: DB_CONV_CTS ciphertexts at a time through plain residues into a ciphertext-major staging image
+    DbConv cv(this, ctm);
+    PinnedBuf buf(DB_CONV_CTS * ctm.ct_bytes);
+    for (size_t t0 = 0; t0 < db_cts; t0 += DB_CONV_CTS) {
+        const size_t cnt = std::min(DB_CONV_CTS, db_cts - t0);
+        db_fetch(t0, cv.plain, (int)cnt);
+        hk::db_pack(stream, N, nQ, cv.plain, cv.image, 0, (int)cnt, ctm);
+        HIP_CHECK(hipMemcpyAsync(buf.p, cv.image, cnt * ctm.ct_bytes, hipMemcpyDeviceToHost, stream));
+        sync();
+        if (fwrite(buf.p, 1, cnt * ctm.ct_bytes, fc.f) != cnt * ctm.ct_bytes) throw std::runtime_error("hydia: write failed (disk full?)");
     }
 }
 void Context::db_load(const char *path) {
@@ -583,7 +620,8 @@ void Context::db_load(const char *path) {
     if ((int)h.logN != prm.logN || (int)h.nQ != nQ || (int)h.dim != prm.dim) throw std::runtime_error("hydia: database file was written for other parameters");
     for (int j = 0; j < nQ; j++)
         if (h.moduli[j] != q[j]) throw std::runtime_error("hydia: database file was written on another prime chain");
-    if ((h.packed != 0) != db_packed || h.ct_bytes != db_layout().ct_bytes)
+    const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);
+    if ((h.packed != 0) != db_packed || h.ct_bytes != ctm.ct_bytes)
         throw std::runtime_error("hydia: database file layout (48-bit packed / 8-byte) differs from this context's");
     if (h.kind != 4 && h.kind != 5 && h.kind != 6) throw std::runtime_error("hydia: database file has an unknown packing kind");
     if (h.kind == 6 && (h.babies < 2 || h.babies >= (uint32_t)prm.dim || (h.babies & (h.babies - 1)) || prm.dim % h.babies))
@@ -607,26 +645,38 @@ void Context::db_load(const char *path) {
     }
     sync_all();  // an earlier, still asynchronous query may be reading the resident database this load overwrites
     db_kind = 0;
-    db_resize(h.n_vectors, h.n_cts);
-    const size_t total = db_cts * db_layout().ct_bytes;
-    PinnedBuf buf(std::min(total, DB_IO_CHUNK));
-    for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
-        const size_t n = std::min(DB_IO_CHUNK, total - off);
-        if (fread(buf.p, 1, n, fc.f) != n) {
-            db_vectors = db_cts = 0;  // nothing usable is resident
-            throw std::runtime_error("hydia: database file is truncated");
+    db_resize(h.n_vectors, h.n_cts, h.kind == 4 ? -1 : (h.kind == 6 ? (int)h.babies : prm.dim));
+    const size_t total = db_cts * ctm.ct_bytes;
+    if (!db_lay.seq) {
+        PinnedBuf buf(std::min(total, DB_IO_CHUNK));
+        for (size_t off = 0; off < total; off += DB_IO_CHUNK) {
+            const size_t n = std::min(DB_IO_CHUNK, total - off);
+            if (fread(buf.p, 1, n, fc.f) != n) {
+                db_vectors = db_cts = 0;  // nothing usable is resident
+                throw std::runtime_error("hydia: database file is truncated");
+            }
+            HIP_CHECK(hipMemcpy(d_db + off, buf.p, n, hipMemcpyHostToDevice));
         }
-        HIP_CHECK(hipMemcpy(d_db + off, buf.p, n, hipMemcpyHostToDevice));
+    } else {
+        DbConv cv(this, ctm);
+        PinnedBuf buf(DB_CONV_CTS * ctm.ct_bytes);
+        for (size_t t0 = 0; t0 < db_cts; t0 += DB_CONV_CTS) {
+            const size_t cnt = std::min(DB_CONV_CTS, db_cts - t0);
+            if (fread(buf.p, 1, cnt * ctm.ct_bytes, fc.f) != cnt * ctm.ct_bytes) {
+                db_vectors = db_cts = 0;
+                throw std::runtime_error("hydia: database file is truncated");
+            }
+            HIP_CHECK(hipMemcpyAsync(cv.image, buf.p, cnt * ctm.ct_bytes, hipMemcpyHostToDevice, stream));
+            hk::db_unpack(stream, N, nQ, cv.plain, cv.image, 0, (int)cnt, ctm);
+            db_store(t0, cv.plain, (int)cnt);
+            sync();  // the pinned buffer is refilled next
+        }
     }
     db_kind = (int)h.kind;
     db_babies = h.kind == 4 ? 0 : (h.babies ? (int)h.babies : prm.dim);
 }
-void Context::db_store(size_t t0, const u64 *d_plain, int X) {
-    hk::db_pack(stream, N, nQ, d_plain, d_db + t0 * db_layout().ct_bytes, X, db_packed ? 1 : 0);
-}
-void Context::db_fetch(size_t t0, u64 *d_plain, int X) {
-    hk::db_unpack(stream, N, nQ, d_plain, d_db + t0 * db_layout().ct_bytes, X, db_packed ? 1 : 0);
-}
+void Context::db_store(size_t t0, const u64 *d_plain, int X) { hk::db_pack(stream, N, nQ, d_plain, d_db, t0, X, db_lay); }
+void Context::db_fetch(size_t t0, u64 *d_plain, int X) { hk::db_unpack(stream, N, nQ, d_plain, d_db, t0, X, db_lay); }
 
 // ------------------------------------------------------------------ kernel timers
 void Context::timer_begin(const char *name) {

@@ -861,7 +861,7 @@ Ct Context::similarity_bsgs_sum(const Ct &qc) {
     // (slot g*G + block), so every later step is ONE batch over all database blocks
     Ct acc(this, G * NG, 3, nl, qc.scale * delta);
     timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G * NG, B, nl, tensor_bpp, tensor_nw, db_packed ? 1 : 0, NG);
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G * NG, B, nl, tensor_bpp, tensor_nw, db_lay, NG);
     timer_end("hydia_tensor");
     relinearize(acc);  // [NG*G][2][nl]
     // giant steps: the partial sums g >= 1 of ALL blocks go through one batched key switch, rotation key B g for slot (g, block)
@@ -1232,7 +1232,7 @@ Ct Context::similarity_accumulate_rot(const Ct &rot) {
     const int G = (int)(db_cts / dim);
     Ct acc(this, G, 3, nQ, rot.scale * delta);
     timer_begin("hydia_tensor");
-    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_packed ? 1 : 0);
+    hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_lay);
     timer_end("hydia_tensor");
     return acc;
 }

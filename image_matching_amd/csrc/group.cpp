@@ -313,13 +313,13 @@ int hydia_group_db_enroll(hydia_group *g, double *db, size_t n, const uint8_t se
         Context &cx = g->shard[r]->cx;
         const size_t first = g->blk_lo[r] * S, last = std::min(g->blk_hi[r] * S, n);
         if (last <= first) {  // more shards than blocks: this one holds nothing
-            cx.db_resize(0, 0);
+            cx.db_resize(0, 0, -1);
             cx.db_kind = 0;
             return;
         }
         const size_t nl = last - first;
         const size_t per = S / dim, nblk = (nl + dim - 1) / dim;
-        cx.db_resize(nl, ((nblk + per - 1) / per) * dim);
+        cx.db_resize(nl, ((nblk + per - 1) / per) * dim, babies);
         client_enroll(cx, db + first * dim, nl, seed, g->blk_lo[r], babies);
         cx.db_kind = babies < (int)dim ? 6 : 5;
         cx.db_babies = babies;

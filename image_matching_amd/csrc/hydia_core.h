@@ -193,10 +193,15 @@ struct Context : HostParams {
     int giants_B = 0, giants_G = 0;  // the tables hold one entry per (giant step g >= 1, database block): x = (g - 1) * G + block
     void build_giants(int G);
     bool db_packed = true;
-    DbLayout db_layout() const { return hk::db_layout(N, nQ, db_packed ? 1 : 0); }
-    void db_resize(size_t n_vectors, size_t cts);         // (re)allocates the resident layout for `cts` ciphertexts
-    // persistence of the resident database (own streaming format: header + the resident layout verbatim, so a restart does not
-    // re-enrol from plaintext; the reference keeps serial/db_diagonal/index<t>.bin, enroller_diag.cpp:158-166)
+    bool db_seq_ok = true;  // many-block hoisted databases take the group-sequential layout (HYDIA_DB_CT_MAJOR turns it off)
+    DbLayout db_lay{};      // layout of the resident database (set by db_resize)
+    DbLayout db_layout() const { return d_db ? db_lay : hk::db_layout(N, nQ, db_packed ? 1 : 0); }
+    // (re)allocates the resident database for `cts` ciphertexts.  form = the hoisted-rotation count its diagonals will be laid out
+    // for (vector_dim = the reference's form, which may take the group-sequential layout; a smaller baby count or -1 for HERS'
+    // column packing stay ciphertext-major)
+    void db_resize(size_t n_vectors, size_t cts, int form);
+    // persistence of the resident database (own streaming format: header + the ciphertext-major layout verbatim, so a restart does
+    // not re-enrol from plaintext; the reference keeps serial/db_diagonal/index<t>.bin, enroller_diag.cpp:158-166)
     void db_save(const char *path);
     void db_load(const char *path);
     void db_store(size_t t0, const u64 *d_plain, int X);  // [X][2][nQ][N] device residues -> ciphertexts t0..t0+X-1

@@ -142,11 +142,18 @@ struct ColFuse {
     u64 t60[HY_CF_TGT];                    // 2^60 mod q_tmod[t] (the FP64 fold of the conversion sums; filled by cf_plan_store)
 };
 
-// resident database layout: ciphertext t at t*ct_bytes, polynomial p at + p*poly_bytes, limb 0 as N 8-byte residues, then
-// (packed) limbs 1.. as N 6-byte residues each — or plain [2][nQ][N] u64 when not packed
+// Resident database layouts.  Residues: limb 0 as 8-byte integers, (packed) limbs 1.. as 6-byte integers — or 8 bytes everywhere.
+//   ciphertext-major (seq = 0): ciphertext t at t*ct_bytes, polynomial p at + p*poly_bytes, limb j at + db_limb_offset(j), coefficients in order.
+//   group-sequential (seq = gs > 0), for databases of many blocks in the hoisted form: the bytes ONE loop-B workgroup reads — a
+//     128-coefficient tile of one limb of gs blocks (gs = waves x blocks per wave of the launch) — form ONE sequential run:
+//     [limb][tile][group of gs blocks][diagonal][block in group][polynomial][128 residues].  HBM serves that pattern at 7.0 TB/s
+//     where the ciphertext-major one (768-byte pieces 4.6 MB apart) gets 6.05 (tools/ubench/stream_rate.hip).
+// Both hold ct_bytes per ciphertext; a ciphertext's address is db_offset() in either.
 struct DbLayout {
     unsigned long long ct_bytes, poly_bytes;
     int packed;
+    int seq, seq_bpp;  // group size gs (0 = ciphertext-major) and the blocks per wave it was chosen with (waves = gs / seq_bpp)
+    int bd, blocks;    // seq: ciphertexts per block (the diagonal count), blocks resident
 };
 
 // ---- device helpers shared by kernels.hip and ntt15.hip: 48-bit packed residues (database, rotation keys of loop A)
@@ -220,9 +227,13 @@ void ledger_enable(bool on);
 void ledger_add(const char *kernel, double bytes);
 size_t ledger_dump(char *out, size_t cap);  // "kernel\tlaunches\tbytes\n" per line; returns the size needed
 
-DbLayout db_layout(int N, int nQ, int packed);
-void db_pack(hipStream_t st, int N, int nQ, const u64 *plain /* [X][2][nQ][N] */, void *db, int X, int packed);
-void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, int X, int packed);
+DbLayout db_layout(int N, int nQ, int packed);                                                     // ciphertext-major
+DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, int nw);          // group-sequential when it applies
+// ciphertexts t0 .. t0+X-1 of the database at `db` <-> plain [X][2][nQ][N] residues
+void db_pack(hipStream_t st, int N, int nQ, const u64 *plain, void *db, size_t t0, int X, const DbLayout &L);
+void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, size_t t0, int X, const DbLayout &L);
+// blocks per wave / waves per workgroup loop B uses for G blocks (bpp, nw = the context's caps)
+void tensor_split(int G, int bpp, int nw, int *B, int *W);
 
 // ---- NTT: X limb-polys of N coefficients; element (x, slot) lives at base + x*outer + slot*N, slot < sel.n
 void ntt_forward(hipStream_t st, const NttTables &T, int logN, const u64 *src, u64 *dst, size_t src_outer,
@@ -334,7 +345,7 @@ void rescale_combine(hipStream_t st, const ModC *mod, int N, const u64 *in, cons
 // ng > 0: the G "blocks" are (database block, giant step) pairs, block-major in the database; accumulator (block, g) is written to
 // slot g * (G / ng) + block (giant-major), so that one giant step's partial sums over all database blocks are one contiguous batch
 void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
-                             int dim, int nl, int bpp, int nw, int packed, int ng = 0);
+                             int dim, int nl, int bpp, int nw, const DbLayout &L, int ng = 0);
 const char *hydia_tensor_kernel_name();
 
 // ---- misc

@@ -12,6 +12,8 @@
 //   k_batch_sum           HERS: sum of the per-dimension products (src/sender/sender_hers.cpp:60-87)
 // No MFMA: this is 64-bit integer modular arithmetic.  HBM-streaming kernels read 16 B per lane (1 KiB per wave
 // instruction) of one limb, so modulus constants are wave-uniform.
+#include <stdexcept>
+
 #include "kernels.h"
 
 #include <algorithm>
@@ -543,6 +545,35 @@ __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict_
 HD size_t db_limb_offset(const DbLayout &L, int N, int j) {
     return L.packed ? (j == 0 ? 0 : (size_t)N * 8 + (size_t)(j - 1) * N * 6) : (size_t)j * N * 8;
 }
+// byte offset of residue c (even: residues travel in pairs) of limb j, polynomial p, ciphertext t
+HD size_t db_offset(const DbLayout &L, int N, size_t t, int p, int j, size_t c) {
+    const size_t es = (L.packed && j > 0) ? 6 : 8;
+    if (!L.seq) return t * L.ct_bytes + (size_t)p * L.poly_bytes + db_limb_offset(L, N, j) + c * es;
+    const size_t g = t / L.bd, i = t % L.bd, grp = g / L.seq, u = g % L.seq, tile = c >> 7, cc = c & 127, groups = L.blocks / L.seq;
+    return (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + ((((tile * groups + grp) * L.bd + i) * L.seq + u) * 2 + p) * 128 * es + cc * es;
+}
+// what a loop-B wave adds to its operand pointer: first byte of (block g0, diagonal 0, polynomial 0, its two residues) and the strides
+// to the next block of the wave, the next diagonal, the other polynomial.  g0 = first block of the wave, grp = its workgroup's group
+struct DbWalk {
+    size_t base, su, si, sp;
+};
+DEV DbWalk db_walk(const DbLayout &L, int N, int dim, int j, int tile, int lane, int g0, int grp, int u0) {
+    const size_t es = (L.packed && j > 0) ? 6 : 8;
+    DbWalk w;
+    if (!L.seq) {
+        w.base = (size_t)g0 * dim * L.ct_bytes + db_limb_offset(L, N, j) + ((size_t)tile * 128 + lane * 2) * es;
+        w.su = (size_t)dim * L.ct_bytes;
+        w.si = L.ct_bytes;
+        w.sp = L.poly_bytes;
+    } else {
+        const size_t groups = L.blocks / L.seq;
+        w.base = (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + ((((size_t)tile * groups + grp) * L.bd) * L.seq + u0) * 256 * es + (size_t)lane * 2 * es;
+        w.su = 256 * es;
+        w.si = (size_t)L.seq * 256 * es;
+        w.sp = 128 * es;
+    }
+    return w;
+}
 // One Karatsuba step per coefficient: d0 += a0 b0, d2 += a1 b1, dk += (a0+a1)(b0+b1); d1 = dk - d0 - d2 at the end.
 // Three 64x64->128 products per coefficient instead of four — loop B is co-bound by the integer multiplier, not only
 // by HBM (gfx950 builds a 128-bit product from four v_mad_u64_u32).
@@ -562,8 +593,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restr
     const size_t ps = (size_t)nl * N, cs = 2 * ps;  // rot / acc poly stride, ciphertext stride (elements)
     const int g0 = (gq * NW + wv) * BPP;
     const u64 *ra = rot + (size_t)j * N + c;
-    const unsigned char *da = db + (size_t)g0 * dim * L.ct_bytes + db_limb_offset(L, N, j) + c * (PK ? 6 : 8);
-    const size_t db_cs = L.ct_bytes, db_ps = L.poly_bytes, db_bs = (size_t)dim * L.ct_bytes;
+    const DbWalk dw = db_walk(L, N, dim, j, tile, lane, g0, gq, wv * BPP);
+    const unsigned char *da = db + dw.base;
+    const size_t db_cs = dw.si, db_ps = dw.sp, db_bs = dw.su;
     const int kbits = M.ks + 2;
     const int chunk = (125 - 2 * kbits >= 30) ? dim : (1 << (125 - 2 * kbits));
     u128 d0x[BPP], d0y[BPP], dkx[BPP], dky[BPP], d2x[BPP], d2y[BPP];
@@ -638,6 +670,125 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor(const ModC *__restr
     }
 }
 
+// Loop B on the packed limbs of a group-sequential database (residues and rotated-query residues below 2^48).  There HBM delivers
+// 7 TB/s and the 128-bit multiply-accumulates above (94 % of the vector issue slots at 6 TB/s) would be the limit, so the products are
+// taken on 24-bit halves, a = ah 2^24 + al, b = bh 2^24 + bl: the partial sums  ll = sum al bl,  mid = sum (al bh + ah bl),
+// hh = sum ah bh  stay below 2^63 for up to 4096 diagonals (Karatsuba's operand sums included: halves below 2^25), so every
+// multiply-accumulate is ONE v_mad_u64_u32 with no carry — 12 per coefficient instead of three 128-bit ones of ~9 instructions each;
+// the 6-byte residues are cut into halves straight from the three loaded dwords.  Same sums, same final reduction.
+// (The halves pass through an empty asm statement: knowing an operand has 24 bits the compiler (ROCm 7.2) forms 24-bit multiplies,
+// drops the masks they make redundant, and then fuses some of them back into v_mad_u64_u32 on the UNMASKED registers — wrong
+// products; tools/ubench/tensor_check.cpp found it.)
+DEV unsigned hide24(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+struct Acc24 {
+    u64 ll, mid, hh;
+    DEV void mac(unsigned al, unsigned ah, unsigned bl, unsigned bh) {
+        ll += (u64)al * bl;
+        mid += (u64)al * bh;
+        mid += (u64)ah * bl;
+        hh += (u64)ah * bh;
+    }
+    DEV u128 wide() const { return (u128)ll + ((u128)mid << 24) + ((u128)hh << 48); }
+};
+template <int BPP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor24(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
+                                                               const unsigned char *__restrict__ db, u64 *__restrict__ acc,
+                                                               int dim, int nl, int Gq, int xcd_map, DbLayout L, int j0, int ng, int nblk) {
+    const int j = blockIdx.y + j0;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int gq = xcd_map ? k % Gq : blockIdx.x % Gq;
+    const int tile = xcd_map ? xcd + 8 * (k / Gq) : blockIdx.x / Gq;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ModC M = mod[j];
+    const size_t c = (size_t)tile * 128 + lane * 2;
+    const size_t ps = (size_t)nl * N, cs = 2 * ps;
+    const int g0 = (gq * NW + wv) * BPP;
+    const u64 *ra = rot + (size_t)j * N + c;
+    const DbWalk dw = db_walk(L, N, dim, j, tile, lane, g0, gq, wv * BPP);
+    const unsigned char *da = db + dw.base;
+    const size_t db_cs = dw.si, db_ps = dw.sp, db_bs = dw.su;
+    Acc24 d0[BPP][2], dk[BPP][2], d2[BPP][2];  // [block][coefficient of the lane's pair]
+#pragma unroll
+    for (int u = 0; u < BPP; u++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) d0[u][e] = dk[u][e] = d2[u][e] = Acc24{0, 0, 0};
+    struct Operands {
+        ulonglong2 a0, a1;
+        DbRaw<true> b0[BPP], b1[BPP];
+    };
+    auto fetch = [&](Operands &o, int i) {
+        o.a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
+        o.a1 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs + ps);
+#pragma unroll
+        for (int u = 0; u < BPP; u++) {
+            o.b0[u].template load<true>(da + u * db_bs + (size_t)i * db_cs);
+            o.b1[u].template load<true>(da + u * db_bs + (size_t)i * db_cs + db_ps);
+        }
+    };
+    auto accumulate = [&](const Operands &o) {
+        // rotated-query residues (8 bytes each, below 2^48): halves of both polynomials and of their sum, shared by the BPP blocks
+        const u64 av[2][2] = {{o.a0.x, o.a0.y}, {o.a1.x, o.a1.y}};
+        unsigned al[2][2], ah[2][2], sl[2], sh[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                al[p][e] = hide24((unsigned)av[p][e] & 0xFFFFFFu);
+                ah[p][e] = __builtin_amdgcn_alignbit((unsigned)(av[p][e] >> 32), (unsigned)av[p][e], 24);
+            }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            sl[e] = al[0][e] + al[1][e];
+            sh[e] = ah[0][e] + ah[1][e];
+        }
+#pragma unroll
+        for (int u = 0; u < BPP; u++) {
+            // database residues: two 48-bit integers in three dwords -> four 24-bit halves per polynomial
+            unsigned bl[2][2], bh[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const auto w = p == 0 ? o.b0[u].w : o.b1[u].w;
+                bl[p][0] = hide24(w.x & 0xFFFFFFu);
+                bh[p][0] = hide24(__builtin_amdgcn_alignbit(w.y, w.x, 24) & 0xFFFFFFu);
+                bl[p][1] = hide24(__builtin_amdgcn_alignbit(w.z, w.y, 16) & 0xFFFFFFu);
+                bh[p][1] = hide24(w.z >> 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                d0[u][e].mac(al[0][e], ah[0][e], bl[0][e], bh[0][e]);
+                d2[u][e].mac(al[1][e], ah[1][e], bl[1][e], bh[1][e]);
+                dk[u][e].mac(sl[e], sh[e], bl[0][e] + bl[1][e], bh[0][e] + bh[1][e]);
+            }
+        }
+    };
+    Operands cur, nxt;
+    fetch(cur, 0);
+    for (int i = 0; i < dim; i += 2) {  // dim is a power of two >= 2; no branch inside (see k_hydia_tensor)
+        fetch(nxt, i + 1);
+        accumulate(cur);
+        if (NW > 1) __builtin_amdgcn_s_barrier();
+        fetch(cur, i + 2 < dim ? i + 2 : i + 1);
+        accumulate(nxt);
+        if (NW > 1) __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int u = 0; u < BPP; u++) {
+        ulonglong2 r0, r1, r2;
+        r0.x = reduce128(d0[u][0].wide(), M); r0.y = reduce128(d0[u][1].wide(), M);
+        r2.x = reduce128(d2[u][0].wide(), M); r2.y = reduce128(d2[u][1].wide(), M);
+        r1.x = submod(submod(reduce128(dk[u][0].wide(), M), r0.x, M.q), r2.x, M.q);
+        r1.y = submod(submod(reduce128(dk[u][1].wide(), M), r0.y, M.q), r2.y, M.q);
+        const int gi = g0 + u, go = ng > 0 ? (gi % ng) * nblk + gi / ng : gi;
+        u64 *o = acc + ((size_t)go * 3 * nl + j) * N + c;
+        *reinterpret_cast<ulonglong2 *>(o) = r0;
+        *reinterpret_cast<ulonglong2 *>(o + ps) = r1;
+        *reinterpret_cast<ulonglong2 *>(o + 2 * ps) = r2;
+    }
+}
+
 // Loop B for SMALL databases (at most 8 blocks on this GPU): the limb-0 launch of k_hydia_tensor has only 256 x G waves, each
 // walking all `dim` diagonals — latency-bound (0.6 ms at G = 1 for 0.5 GB).  Here KS waves of a workgroup share one
 // (block, tile) and take every KS-th diagonal; the partial sums are reduced modulo q_j through LDS.  Same residues as the
@@ -701,12 +852,12 @@ __global__ __launch_bounds__(64 * KS) void k_hydia_tensor_sk(const ModC *__restr
 // unpacked [X][2][nQ][N] u64  <->  database layout.  grid (N/512, nQ, X*2)
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_db_repack(int N, int nQ, u64 *__restrict__ plain, unsigned char *__restrict__ db,
-                                                   DbLayout L) {
+                                                   DbLayout L, size_t t0) {
     const int j = blockIdx.y, xp = blockIdx.z, x = xp >> 1, p = xp & 1;
     const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
     u64 *pl = plain + ((size_t)xp * nQ + j) * N + c;
     const bool pk = L.packed && j > 0;
-    unsigned char *d = db + (size_t)x * L.ct_bytes + (size_t)p * L.poly_bytes + db_limb_offset(L, N, j) + c * (pk ? 6 : 8);
+    unsigned char *d = db + db_offset(L, N, t0 + x, p, j, c);
     typedef unsigned int u3 __attribute__((ext_vector_type(3), aligned(4)));
     if (PACK) {
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pl);
@@ -929,12 +1080,13 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
     const int xm = (N / 128) % 8 == 0 ? 1 : 0;  // XCD-aware tile -> workgroup map
     const unsigned char *dbb = (const unsigned char *)db;
     const dim3 blk(64 * NW);
+    const bool h24 = L.packed && L.seq && dim <= 4096;  // the 24-bit-halves kernel: its partial sums hold 4096 diagonals
     {   // resident database (6- or 8-byte residues) + rotated queries once + accumulators, split limb 0 / other limbs like the launches
         const double per_lp6 = (double)N * 6.0, per_lp8 = LP_BYTES(N);
         const double rot_acc = (double)dim * 2 * per_lp8 + (double)G * 3 * per_lp8;
         char n0[64], n1[64];
         snprintf(n0, sizeof n0, "k_hydia_tensor<%d, %d, true, false>", BPP, NW);
-        snprintf(n1, sizeof n1, "k_hydia_tensor<%d, %d, true, true>", BPP, NW);
+        snprintf(n1, sizeof n1, h24 ? "k_hydia_tensor24<%d, %d>" : "k_hydia_tensor<%d, %d, true, true>", BPP, NW);
         if (L.packed && G <= 8) snprintf(n0, sizeof n0, "k_hydia_tensor_sk<%d, false>", G <= 2 ? 16 : 4);
         if (L.packed) {
             ledger_add(n0, (double)G * dim * 2 * per_lp8 + rot_acc);
@@ -951,7 +1103,10 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
         else
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
                                Gq, xm, L, 0, ng, nblk);
-        if (nl > 1)
+        if (nl > 1 && h24)
+            hipLaunchKernelGGL((k_hydia_tensor24<BPP, NW>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl, Gq, xm, L,
+                               1, ng, nblk);
+        else if (nl > 1)
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, true>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc,
                                dim, nl, Gq, xm, L, 1, ng, nblk);
     } else {
@@ -960,10 +1115,8 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
     }
 }
 // bpp = database blocks per wave, nw = max waves per workgroup (0: up to 16); both must divide G
-void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
-                             int dim, int nl, int bpp, int nw, int packed, int ng) {
-    DbLayout L = db_layout(N, nl, packed);
-    int B = (bpp >= 4 && G % 4 == 0) ? 4 : (bpp >= 2 && G % 2 == 0) ? 2 : 1;
+void tensor_split(int G, int bpp, int nw, int *Bo, int *Wo) {
+    const int B = (bpp >= 4 && G % 4 == 0) ? 4 : (bpp >= 2 && G % 2 == 0) ? 2 : 1;
     const int rest = G / B;
     int W = 1;
     for (int cand : {16, 8, 4, 2})
@@ -971,27 +1124,53 @@ void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *
             W = cand;
             break;
         }
+    *Bo = B;
+    *Wo = W;
+}
+void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *rot, const void *db, u64 *acc, int G,
+                             int dim, int nl, int bpp, int nw, const DbLayout &L, int ng) {
+    int B, W;
+    tensor_split(G, bpp, nw, &B, &W);
+    if (L.seq) {  // the layout fixes the workgroup's share: a group of the database is what one workgroup walks
+        if (G != L.blocks || dim != L.bd || ng != 0 || L.seq % L.seq_bpp || G % L.seq || G <= 8)
+            throw std::logic_error("hydia: loop B launched against a group-sequential database with another shape");
+        B = L.seq_bpp;
+        W = L.seq / L.seq_bpp;
+    }
 #define HY_TENSOR_CASE(b, w) \
     if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl, L, ng);
     HY_TENSOR_CASE(4, 16) HY_TENSOR_CASE(4, 8) HY_TENSOR_CASE(4, 4) HY_TENSOR_CASE(4, 2) HY_TENSOR_CASE(4, 1)
     HY_TENSOR_CASE(2, 16) HY_TENSOR_CASE(2, 8) HY_TENSOR_CASE(2, 4) HY_TENSOR_CASE(2, 2) HY_TENSOR_CASE(2, 1)
     HY_TENSOR_CASE(1, 16) HY_TENSOR_CASE(1, 8) HY_TENSOR_CASE(1, 4) HY_TENSOR_CASE(1, 2) HY_TENSOR_CASE(1, 1)
 #undef HY_TENSOR_CASE
+    throw std::logic_error("hydia: no loop B kernel for this split");
 }
 DbLayout db_layout(int N, int nQ, int packed) {
-    DbLayout L;
+    DbLayout L{};
     L.packed = packed;
     L.poly_bytes = packed ? (unsigned long long)N * 8 + (unsigned long long)(nQ - 1) * N * 6 : (unsigned long long)nQ * N * 8;
     L.ct_bytes = 2 * L.poly_bytes;
     return L;
 }
-void db_pack(hipStream_t st, int N, int nQ, const u64 *plain, void *db, int X, int packed) {
-    hipLaunchKernelGGL(k_db_repack<true>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, const_cast<u64 *>(plain),
-                       (unsigned char *)db, db_layout(N, nQ, packed));
+// group-sequential for `blocks` blocks of bd ciphertexts: only where loop B is a stream worth shaping (more than 8 blocks, whole
+// 128-residue tiles) — otherwise the ciphertext-major layout comes back
+DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, int nw) {
+    DbLayout L = db_layout(N, nQ, packed);
+    if (blocks <= 8 || N % 128) return L;
+    int B, W;
+    tensor_split(blocks, bpp, nw, &B, &W);
+    L.seq = B * W;
+    L.seq_bpp = B;
+    L.bd = bd;
+    L.blocks = blocks;
+    return L;
 }
-void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, int X, int packed) {
-    hipLaunchKernelGGL(k_db_repack<false>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, plain, (unsigned char *)db,
-                       db_layout(N, nQ, packed));
+void db_pack(hipStream_t st, int N, int nQ, const u64 *plain, void *db, size_t t0, int X, const DbLayout &L) {
+    hipLaunchKernelGGL(k_db_repack<true>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, const_cast<u64 *>(plain),
+                       (unsigned char *)db, L, t0);
+}
+void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, size_t t0, int X, const DbLayout &L) {
+    hipLaunchKernelGGL(k_db_repack<false>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, plain, (unsigned char *)db, L, t0);
 }
 const char *hydia_tensor_kernel_name() { return "k_hydia_tensor"; }
 void fill_uniform_hash(hipStream_t st, const ModC *mod, int N, u64 *dst, size_t n_limbpolys, int nl,

@@ -117,6 +117,7 @@ def load_library():
         "hydia_set_matvec": (i32, [vp, i32]),
         "hydia_get_matvec": (i32, [vp]),
         "hydia_db_kind": (i32, [vp]),
+        "hydia_db_group": (i32, [vp]),
         "hydia_db_babies": (i32, [vp]),
         "hydia_db_set_babies": (i32, [vp, i32]),
         "hydia_auto_babies": (i32, [vp, sz]),
@@ -501,6 +502,10 @@ class Context:
     def auto_babies(self, blocks):
         """what an enrolment of `blocks` 16384-vector blocks on this context would pick (its policy applied)"""
         return int(self.L.hydia_auto_babies(self.h, blocks))
+
+    def db_group(self):
+        """0: the resident database is ciphertext-major; g > 0: group-sequential with groups of g blocks (hydia_db_group)"""
+        return int(self.L.hydia_db_group(self.h))
 
     def db_stats(self):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()

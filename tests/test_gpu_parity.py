@@ -367,3 +367,59 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     for r in results[1:]:
         for a, b in zip(results[0], r):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("blocks,group", [(10, 2), (16, 8)])
+def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group, tmp_path, monkeypatch):
+    """A hoisted database of more than 8 blocks lies group-sequentially in HBM (loop B's 24-bit-halves kernel reads
+    it).  Same ciphertexts in, same ciphertexts out as the oracle — through the GPU enroller and through ciphertext-by-ciphertext
+    import; export, save / load (the file is ciphertext-major whatever the resident layout) and a ciphertext-major context agree."""
+    P, K, Or, cc = small
+    n = blocks * P.slots - 3
+    rng = np.random.default_rng(blocks)
+    db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
+    for i in (0, n // 2, n - 1):
+        db[i] = rng.integers(1, 4, size=P.dim)
+    query = np.ones(P.dim)
+    dbc = Or.enroll(db.copy(), 41, matvec="hoisted")
+    q = Or.encrypt_query(query, 5, 1)
+    sim = Or.compute_similarity(q, dbc, n)
+    gq = cc.import_ct(q.data(), q.scale)
+    cc.set_matvec("hoisted")
+    try:
+        im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=41)
+        assert cc.db_group() == group and cc.db_kind() == 5
+        for t in (0, 1, P.dim - 1, P.dim, len(dbc) // 2 + 3, len(dbc) - 1):
+            assert np.array_equal(cc.db_export_ct(t), dbc[t].data()), t
+        sender = im.DiagonalSender(cc, n)
+        gs = sender.computeSimilarity(gq).export()
+        for g in range(blocks):
+            assert np.array_equal(gs[g], sim[g].data()), g
+        want_idx = sender.indexScenario(gq).export()
+        # (64-dimensional random rows cross the 0.44 threshold by chance now and then: the planted matches must be among the hits)
+        assert {0, n // 2, n - 1} <= set(im.DiagonalReceiver(cc, n).decryptIndex(sender.indexScenario(gq)))
+        with pytest.raises(im.HydiaError):  # pre-rotated diagonals cannot be declared on a database laid out for the hoisted form
+            cc.db_set_babies(8)
+        path = str(tmp_path / "db.bin")
+        cc.db_save(path)
+        # ciphertext by ciphertext (the adapter's path), then the file, into the same context
+        load_db(cc, dbc, n)
+        assert cc.db_group() == group
+        assert np.array_equal(sender.computeSimilarity(gq).export(), gs)
+        cc.db_load(path)
+        assert cc.db_group() == group and cc.db_stats()[0] == n
+        assert np.array_equal(sender.indexScenario(gq).export(), want_idx)
+        # a context that keeps every database ciphertext-major reads the same file and computes the same ciphertexts
+        monkeypatch.setenv("HYDIA_DB_CT_MAJOR", "1")
+        c2 = make_ctx(im, P)
+        monkeypatch.delenv("HYDIA_DB_CT_MAJOR")
+        load_keys(c2, K, K.rotations)
+        c2.set_matvec("hoisted")
+        c2.db_load(path)
+        assert c2.db_group() == 0
+        g2 = c2.import_ct(q.data(), q.scale)
+        assert np.array_equal(im.DiagonalSender(c2, n).indexScenario(g2).export(), want_idx)
+        c2.db_set_babies(P.dim)  # a no-op declaration stays legal
+        c2.close()
+    finally:
+        cc.set_matvec("auto")

@@ -1,5 +1,5 @@
 // tools/ubench/tensor_check.cpp — loop B's kernels against a host recomputation on random residues, small ring (debugging aid:
-// it isolated a ROCm 7.2 miscompile of 24-bit multiply-accumulates in an experimental kernel).  Usage: tensor_check <blocks> <dim>
+// it isolated a ROCm 7.2 miscompile of 24-bit multiply-accumulates in an experimental kernel).  Usage: tensor_check <blocks> <dim> [1 = group-sequential layout]
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I image_matching_amd/csrc -I include tools/ubench/tensor_check.cpp -L image_matching_amd -lhydia -Wl,-rpath,$PWD/image_matching_amd -o tools/ubench/tensor_check
 #include <cstdio>
 #include <vector>
@@ -16,15 +16,17 @@ int main(int argc, char **argv) {
     const size_t ct = (size_t)2 * nl * N;
     u64 *rot, *plain, *acc;
     void *db;
-    const DbLayout L = hk::db_layout(N, nl, 1);
+    const bool seq = argc > 3 && atoi(argv[3]) != 0;  // third argument 1: the group-sequential layout (more than 8 blocks)
+    const DbLayout L = seq ? hk::db_layout_seq(N, nl, 1, dim, G, 2, 4) : hk::db_layout(N, nl, 1);
+    printf("layout: %s (group of %d blocks)\n", L.seq ? "group-sequential" : "ciphertext-major", L.seq);
     hipMalloc((void **)&rot, ct * dim * 8);
     hipMalloc((void **)&plain, ct * dim * G * 8);
     hipMalloc(&db, (size_t)L.ct_bytes * dim * G);
     hipMalloc((void **)&acc, (size_t)G * 3 * nl * N * 8);
     hk::fill_uniform_hash(cx.stream, cx.d_mod, N, rot, (size_t)2 * nl * dim, nl, 11);
     hk::fill_uniform_hash(cx.stream, cx.d_mod, N, plain, (size_t)2 * nl * dim * G, nl, 12);
-    hk::db_pack(cx.stream, N, nl, plain, db, dim * G, 1);
-    hk::hydia_tensor_accumulate(cx.stream, cx.d_mod, N, rot, db, acc, G, dim, nl, 2, 4, 1, 0);
+    hk::db_pack(cx.stream, N, nl, plain, db, 0, dim * G, L);
+    hk::hydia_tensor_accumulate(cx.stream, cx.d_mod, N, rot, db, acc, G, dim, nl, 2, 4, L, 0);
     hipStreamSynchronize(cx.stream);
     std::vector<u64> hr(ct * dim), hp(ct * dim * G), ha((size_t)G * 3 * nl * N);
     hipMemcpy(hr.data(), rot, hr.size() * 8, hipMemcpyDeviceToHost);
