@@ -536,9 +536,10 @@ void Context::db_resize(size_t n_vectors, size_t cts, int form) {
     if (!d_db && bytes) HIP_CHECK(hipMalloc((void **)&d_db, bytes));
     db_cts = cts;
     db_vectors = n_vectors;
-    const size_t dim = (size_t)prm.dim;
-    db_lay = (db_seq_ok && db_packed && form == prm.dim && cts % dim == 0)
-                 ? hk::db_layout_seq(N, nQ, 1, prm.dim, (int)(cts / dim), tensor_bpp, tensor_nw)
+    // loop B walks "blocks" of `form` ciphertexts (the hoisted rotations per query: vector_dim, or the baby count of a pre-rotated
+    // database, whose blocks are the (database block, giant step) pairs)
+    db_lay = (db_seq_ok && db_packed && form >= 2 && cts % (size_t)form == 0)
+                 ? hk::db_layout_seq(N, nQ, 1, form, (int)(cts / (size_t)form), tensor_bpp, tensor_nw)
                  : ctm;
 }
 namespace {

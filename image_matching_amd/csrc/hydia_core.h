@@ -197,8 +197,8 @@ struct Context : HostParams {
     DbLayout db_lay{};      // layout of the resident database (set by db_resize)
     DbLayout db_layout() const { return d_db ? db_lay : hk::db_layout(N, nQ, db_packed ? 1 : 0); }
     // (re)allocates the resident database for `cts` ciphertexts.  form = the hoisted-rotation count its diagonals will be laid out
-    // for (vector_dim = the reference's form, which may take the group-sequential layout; a smaller baby count or -1 for HERS'
-    // column packing stay ciphertext-major)
+    // for (vector_dim = the reference's form, or the baby count): loop B walks blocks of `form` ciphertexts, and more than 8 of them
+    // take the group-sequential layout; -1 (HERS' column packing) stays ciphertext-major
     void db_resize(size_t n_vectors, size_t cts, int form);
     // persistence of the resident database (own streaming format: header + the ciphertext-major layout verbatim, so a restart does
     // not re-enrol from plaintext; the reference keeps serial/db_diagonal/index<t>.bin, enroller_diag.cpp:158-166)

@@ -1132,7 +1132,7 @@ void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *
     int B, W;
     tensor_split(G, bpp, nw, &B, &W);
     if (L.seq) {  // the layout fixes the workgroup's share: a group of the database is what one workgroup walks
-        if (G != L.blocks || dim != L.bd || ng != 0 || L.seq % L.seq_bpp || G % L.seq || G <= 8)
+        if (G != L.blocks || dim != L.bd || L.seq % L.seq_bpp || G % L.seq || G <= 8)
             throw std::logic_error("hydia: loop B launched against a group-sequential database with another shape");
         B = L.seq_bpp;
         W = L.seq / L.seq_bpp;

@@ -12,16 +12,17 @@ sys.path.insert(0, ROOT)
 import image_matching_amd as im  # noqa: E402
 
 MAXLG = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+BLOCKS = [int(v) for v in sys.argv[2].split()] if len(sys.argv) > 2 else [1 << lg for lg in range(MAXLG + 1)]
+BABIES = [int(v) for v in sys.argv[3].split()] if len(sys.argv) > 3 else [32, 64, 128, 256, 512]
 cc = im.Context()
 cc.fill_eval_keys_random(1)
 rng = np.random.default_rng(0)
 q = np.stack([rng.integers(0, int(m), size=(2, cc.N), dtype=np.uint64) for m in cc.moduli[:cc.nQ]], axis=1)
 gq = cc.import_ct(q, cc.delta)
-lines = ["blocks  " + "  ".join("B=%-6d" % b for b in (32, 64, 128, 256, 512)) + "  auto"]
-for lg in range(0, MAXLG + 1):
-    G = 1 << lg
+lines = ["blocks  " + "  ".join("B=%-6d" % b for b in BABIES) + "  auto"]
+for G in BLOCKS:
     row = []
-    for B in (32, 64, 128, 256, 512):
+    for B in BABIES:
         cc.set_matvec("hoisted" if B == 512 else B)
         cc.db_fill_random(G * 16384, 2)
         assert cc.db_babies() == B
