@@ -381,7 +381,7 @@ def main():
         wire = resident_bytes / avg_launch_s / 1e9 if launches else 0.0
         traffic = traffic_meta = None
         tpath = os.path.join(ROOT, "profiles", "tensor_traffic.json")
-        knobs = [k for k in ("HYDIA_DB_UNPACKED", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW") if os.environ.get(k)]
+        knobs = [k for k in ("HYDIA_DB_UNPACKED", "HYDIA_DB_CT_MAJOR", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW") if os.environ.get(k)]
         if os.path.exists(tpath) and not args.random_db and not knobs and world == 1:
             try:
                 tj = json.load(open(tpath))
@@ -404,8 +404,9 @@ def main():
             "vs_baseline": (n_total * args.steps / elapsed) / PUBLISHED_2P20_INDEX_VPS if (world == 1 and n_total == 1 << 20) else None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_name(n_total, world, strong) + ": %d blocks of 16384 vectors on this GPU (%.0f GiB resident in "
-                                   "HBM as 48-bit residues = %.0f GiB of 8-byte ciphertexts), one query per step through indexScenario"
-                                   % (G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30),
+                                   "HBM as 48-bit residues = %.0f GiB of 8-byte ciphertexts, %s), one query per step through indexScenario"
+                                   % (G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30,
+                                      ("group-sequential layout, groups of %d blocks" % cc.db_group()) if cc.db_group() else "ciphertext-major layout"),
                        "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
                        "matvec": ("baby-step / giant-step: %d hoisted rotations of the query, %d relinearised partial sums per block rotated by "
@@ -428,13 +429,15 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
                          "wire": {"bytes_per_launch": resident_bytes, "achieved": wire, "frac": wire / HBM_PEAK_GBS,
                                   "what": "resident-layout bytes (6-byte residues for the 45/46-bit limbs) / launch time: the rate HBM "
-                                          "actually has to sustain; against the guide's measured 6.29 TB/s copy ceiling this is %.2f"
-                                          % (wire / 6290.0)},
+                                          "actually has to sustain; against 7.05 TB/s, what this GPU gives a read-once sequential stream "
+                                          "(tools/ubench/stream_rate.hip, profiles/r03/stream_rate.txt; the guide's copy ceiling is 6.29), "
+                                          "this is %.2f" % (wire / 7050.0)},
                          "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8d (196608 B per DB vector at 8 B per residue + rotated "
                                  "queries + accumulators); one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two "
-                                 "kernels, timed together with HIP events on the library's stream); `wire` is the same launch priced "
-                                 "at the bytes resident in HBM; `traffic` = PMC HBM bytes per launch (profiles/tensor_traffic.json), quoted "
-                                 "only while the kernel source it was profiled on is unchanged"},
+                                 "kernels, timed together with HIP events on the library's stream).  The database holds the 45/46-bit "
+                                 "limbs as 6-byte residues, so frac can pass 1.0: `wire` is the same launch priced at the bytes resident "
+                                 "in HBM (the honest utilisation); `traffic` = PMC HBM bytes per launch (profiles/tensor_traffic.json), "
+                                 "quoted only while the kernel source it was profiled on is unchanged"},
         }
         if weak is not None:
             out["config"]["secondary"] = {"weak_scaling": weak}
@@ -477,13 +480,15 @@ def kernel_sha():
     h = hashlib.sha256()
     src = os.path.join(ROOT, "image_matching_amd", "csrc")
     text = open(os.path.join(src, "kernels.hip")).read()
-    a = text.find("template <int BPP, int NW, bool NT, bool PK>")
-    b = text.find("\n}\n", a)
-    h.update(text[a:b].encode())
+    for start in ("template <int BPP, int NW, bool NT, bool PK>", "struct Acc24 {", "DEV DbWalk db_walk("):  # both loop-B kernels, the layout walk
+        a = text.find(start)
+        b = text.find("\n}\n", text.find("__global__", a) if "template" in start or "Acc24" in start else a)
+        h.update(text[a:b].encode())
     hdr = open(os.path.join(src, "kernels.h")).read()
-    a = hdr.find("DEV ulonglong2 db_load2")
-    b = hdr.find("\n}\n", a)
-    h.update(hdr[a:b].encode())
+    for start in ("DEV ulonglong2 db_load2", "struct DbRaw<true>"):
+        a = hdr.find(start)
+        b = hdr.find("\n}", a)
+        h.update(hdr[a:b].encode())
     return h.hexdigest()[:16]
 
 

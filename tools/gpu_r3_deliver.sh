@@ -1,6 +1,7 @@
 # Round-3 deliverables on the GPU box: full GPU suite, smoke, CLI, bench (+ CPU baseline), fixed-cost sizes, per-kernel byte tables
 # (2^20; 2^14 in both forms of the mat-vec; loop A alone), SQ counters of loop A, PMC traffic of loop B, the one-GPU components of the
-# multi-GPU step model, multi-rank rehearsals of bench.py on the one GPU
+# multi-GPU step model, multi-rank rehearsals of bench.py on the one GPU, the streaming-rate microbenchmark and loop B's host check
+# (tools/ubench/stream_rate, tools/ubench/tensor_check: built in the container, they travel with the snapshot)
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -15,6 +16,7 @@ for l in 10 14 17; do timeout -k 10 300 python bench.py --steps 10 --warmup 3 --
 import json; d=json.load(open('gpurun_out/bench_2p$l.json')); print('2^$l:', round(d['value']), 'vec/s', round(d['ms_per_step'],2), 'ms/step', d['config']['result_correct'])"; done
 HYDIA_BENCH_FORCE_DIST=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_forcedist.json 2> gpurun_out/bench_forcedist.err || exit 1
 HYDIA_BENCH_REHEARSE=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 3 --warmup 1 --total-log2n 17 --log2n 16 --no-cpu-baseline > gpurun_out/bench_rehearse2.json 2> gpurun_out/bench_rehearse2.err || exit 1
+(timeout -k 10 200 tools/ubench/stream_rate > gpurun_out/stream_rate.txt 2>&1 && for a in "16 64 0" "16 64 1" "20 8 1"; do timeout -k 10 100 tools/ubench/tensor_check $a; done > gpurun_out/tensor_check.txt 2>&1) || { tail -3 gpurun_out/stream_rate.txt gpurun_out/tensor_check.txt; exit 1; }; tail -8 gpurun_out/stream_rate.txt
 timeout -k 10 300 python tools/prof_scaling_components.py 20 > gpurun_out/scaling_components.log 2>&1 && timeout -k 10 300 python tools/prof_scaling_components.py 17 >> gpurun_out/scaling_components.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench_stats.log 2>&1 || exit 1
