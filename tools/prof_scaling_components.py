@@ -46,10 +46,11 @@ for R in (1, 2, 4, 8):
     t_full = timed(lambda: snd.indexScenario(gq))
     row = {"blocks_per_gpu": G, "loop_a_share_ms": round(t_a, 3), "rest_on_given_rotations_ms": round(t_rest, 3),
            "whole_query_replicated_loop_a_ms": round(t_full, 3)}
-    if G <= 8:
-        cc.set_matvec("bsgs")
+    cc.set_matvec("auto")
+    if cc.auto_babies(G) < cc.dim:  # the split the auto rule picks for this many blocks, when it is not the hoisted form timed above
         cc.db_fill_random(G * 16384, 2)
-        row["whole_query_bsgs_ms"] = round(timed(lambda: snd.indexScenario(gq)), 3)
+        row["auto_babies"] = cc.db_babies()
+        row["whole_query_auto_split_ms"] = round(timed(lambda: snd.indexScenario(gq)), 3)
     out["ranks"][R] = row
     print(R, row, flush=True)
     del rot, gq, snd
