@@ -17,11 +17,12 @@ r, s = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
 q = r.encryptQuery(np.ones(512), seed=5)
 ref = s.indexScenario(q).export()
 mem0 = None
+every = min(50, max(1, iters // 2))  # at least two checkpoints
 t0 = time.time()
 for i in range(iters):
     which = i % 3
     out = s.indexScenario(q) if which == 0 else (s.membershipScenario(q) if which == 1 else s.computeSimilarity(q))
-    if i % 50 == 49:
+    if i % every == every - 1:
         cc.sync()
         live, cached, peak = cc.memory_stats()
         same = np.array_equal(s.indexScenario(q).export(), ref)
