@@ -369,12 +369,20 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("blocks,group", [(10, 2), (16, 8)])
-def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group, tmp_path, monkeypatch):
+@pytest.mark.parametrize("blocks,group,env", [(10, 2, {}), (16, 8, {}), (12, 4, {"HYDIA_TENSOR_BPP": "1"})])
+def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group, env, tmp_path, monkeypatch):
     """A hoisted database of more than 8 blocks lies group-sequentially in HBM (loop B's 24-bit-halves kernel reads
     it).  Same ciphertexts in, same ciphertexts out as the oracle — through the GPU enroller and through ciphertext-by-ciphertext
     import; export, save / load (the file is ciphertext-major whatever the resident layout) and a ciphertext-major context agree."""
     P, K, Or, cc = small
+    own = None
+    if env:  # another loop-B tiling = another group shape: the layout is fixed by the context that allocates the database
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cc = own = make_ctx(im, P)
+        for k in env:
+            monkeypatch.delenv(k)
+        load_keys(cc, K, K.rotations)
     n = blocks * P.slots - 3
     rng = np.random.default_rng(blocks)
     db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
@@ -423,3 +431,5 @@ def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group
         c2.close()
     finally:
         cc.set_matvec("auto")
+        if own is not None:
+            own.close()
