@@ -447,13 +447,23 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     }
 }
 
+// The LDS image of a pass-2 workgroup: 8 blocks x 8 rows x 32 coefficients per polynomial.  Padded (rows of 36: phase B's (row, 4k + b)
+// accesses of a half-wave hit 32 distinct bank pairs) or, SWZ, unpadded with the position XOR-ed by 4 x row — the same property at
+// 16 KiB instead of 18 per polynomial, which lets the three-digit fused inner product keep THREE workgroups on a CU (3 x 48 KiB) where
+// the padded image allows two; a few more address instructions per access, so only that kernel takes it.
+template <bool SWZ>
+struct P2Lds {
+    static constexpr int SIZE = SWZ ? 8 * 256 : 8 * 288;
+    DEV static int at(int blk, int row, int pos) { return SWZ ? blk * 256 + row * 32 + (pos ^ (row << 2)) : blk * 288 + row * 36 + pos; }
+};
+
 // phases B' and A' of the inverse second pass for NPI polynomials whose phase-C' output sits in lds (caller synchronised)
-template <class A, int NPI>
-DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[8 * 288], u64 *const *d, int t, int B0) {
+template <class A, int NPI, bool SWZ = false>
+DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[P2Lds<SWZ>::SIZE], u64 *const *d, int t, int B0) {
     typedef typename A::T T;
     typedef typename A::TW TW;
+    typedef P2Lds<SWZ> LI;
     constexpr int NP = NPI;
-    constexpr int LROW = 36, LBLK = 8 * LROW;
     const int blk = t >> 5, w = t & 31;
     const int bg = (B0 >> 8) + blk;
     const int a = w >> 2, b = w & 3;
@@ -469,7 +479,7 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + a * LROW + 4 * k + b]);
+            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][LI::at(blk, a, 4 * k + b)]);
 #pragma unroll
             for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W12[k >> 1]);
             ar.gs(v[p][0], v[p][2], W11a);
@@ -481,7 +491,7 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 ar.recentre(v[p][k]);
-                lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
+                lds[p][LI::at(blk, a, 4 * k + b)] = A::to_bits(v[p][k]);
             }
         }
     }
@@ -496,7 +506,7 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + k * LROW + w]);
+            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][LI::at(blk, k, w)]);
 #pragma unroll
             for (int k = 0; k < 8; k += 2) ar.gs(v[p][k], v[p][k + 1], W9[k >> 1]);
             ar.gs(v[p][0], v[p][2], W8a);
@@ -520,13 +530,13 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
 // ST 6 = ST 4 for the special-prime limbs with the inverse transform's second pass appended: the two sums of a lane's four
 // coefficients go through phase C' in registers and meet the other lanes' in lds[0], lds[1] (the digits' images there are dead by
 // then: every lane reads and overwrites only its own four slots), phases B', A' follow, the raw image leaves through dinv.
-template <class A, bool INV, int NP, int ST>
-DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const *s, u64 *const *d, u64 (*lds)[8 * 288], int t,
+template <class A, bool INV, int NP, int ST, bool SWZ = false>
+DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const *s, u64 *const *d, u64 (*lds)[P2Lds<SWZ>::SIZE], int t,
                  int B0, const NttStore &stp, const ModC &M, int xp0, int slot, const ulonglong2 *__restrict__ itw = nullptr,
                  u64 *const *dinv = nullptr) {
     typedef typename A::T T;
     typedef typename A::TW TW;
-    constexpr int LROW = 36, LBLK = 8 * LROW;
+    typedef P2Lds<SWZ> LI;
     const int blk = t >> 5, w = t & 31;
     const int bg = (B0 >> 8) + blk;
     const int a = w >> 2, b = w & 3;
@@ -554,7 +564,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) ar.ct(v[p][k], v[p][k + 1], W9[k >> 1]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + k * LROW + w] = A::to_bits(v[p][k]);
+                for (int k = 0; k < 8; k++) lds[p][LI::at(blk, k, w)] = A::to_bits(v[p][k]);
             }
         }
         __syncthreads();
@@ -569,7 +579,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][blk * LBLK + a * LROW + 4 * k + b]);
+                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][LI::at(blk, a, 4 * k + b)]);
 #pragma unroll
                 for (int k = 0; k < 4; k++) ar.ct(v[p][k], v[p][k + 4], W10);
                 ar.ct(v[p][0], v[p][2], W11a);
@@ -579,7 +589,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) ar.ct(v[p][k], v[p][k + 1], W12[k >> 1]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) lds[p][blk * LBLK + a * LROW + 4 * k + b] = A::to_bits(v[p][k]);
+                for (int k = 0; k < 8; k++) lds[p][LI::at(blk, a, 4 * k + b)] = A::to_bits(v[p][k]);
             }
         }
         // the merged epilogues' operands are fetched one half at a time (the second half's while the first half is finished): 109 / 120
@@ -596,7 +606,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int e = 4 * t + 1024 * hh, u = e & 255, la = (e >> 8) * LBLK + (u >> 5) * LROW + (u & 31);
+            const int e = 4 * t + 1024 * hh, u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
             // mode 4: lazy 128-bit sums of value * key over the digits this workgroup transforms (+ the limb's own digit)
@@ -676,13 +686,13 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         }
         if (ST == 6) {
             __syncthreads();
-            p2_inverse_BA<A, 2>(ar, itw, lds, dinv, t, B0);
+            p2_inverse_BA<A, 2, SWZ>(ar, itw, lds, dinv, t, B0);
         }
     } else {
         // phase C': strides 1, 2
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int e = 4 * t + 1024 * hh, u = e & 255, la = (e >> 8) * LBLK + (u >> 5) * LROW + (u & 31);
+            const int e = 4 * t + 1024 * hh, u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
 #pragma unroll
@@ -719,7 +729,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             }
         }
         __syncthreads();
-        p2_inverse_BA<A, NP>(ar, tw, lds, d, t, B0);
+        p2_inverse_BA<A, NP, SWZ>(ar, tw, lds, d, t, B0);
     }
 }
 
@@ -730,7 +740,10 @@ template <bool INV, int NP, int ST>
 __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : 1) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
                                                   size_t dso, LimbSel sel, int slot0, int nsl, NttStore stp) {
     constexpr int N = 32768;
-    __shared__ u64 lds[NP][8 * 288];
+    // (the unpadded image would let five two-polynomial workgroups share a CU instead of four: measured, no gain — 4.05 vs 4.08 ms for
+    // the merged epilogue's 23 launches of a 2^20 query — so the plain transforms keep the padded one)
+    constexpr bool SWZ = false;
+    __shared__ u64 lds[NP][P2Lds<SWZ>::SIZE];
     const int y = blockIdx.y;
     const int xp = y / nsl, slot = slot0 + (y - xp * nsl), m = sel.mod[slot];
     const ModC M = T.mod[m];
@@ -744,16 +757,16 @@ __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : 1) void k_ntt15_p2(Ntt
         s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;
         d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;
     }
-    if (fp) p2_body<FpA, INV, NP, ST>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
-    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
-    else p2_body<IntA, INV, NP, ST>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    if (fp) p2_body<FpA, INV, NP, ST, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST, SWZ>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    else p2_body<IntA, INV, NP, ST, SWZ>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
 }
 
 // second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
 // workgroups that share a key tile follow each other.  Limb t = t0 + slot; the NP digits are all digits but the limb's own.
-template <int NP, bool OWN, bool TAIL>
+template <int NP, bool OWN, bool TAIL, bool SWZ = false>
 DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t dxs, int t, int x, const NttStore &stp, int bx,
-                         u64 (*lds)[8 * 288]) {
+                         u64 (*lds)[P2Lds<SWZ>::SIZE]) {
     constexpr int N = 32768;
     const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
     const ModC M = T.mod[m];
@@ -775,14 +788,14 @@ DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t
 #pragma unroll
         for (int pp = 0; pp < 2; pp++)
             dinv[pp] = stp.ip.inv_out + (size_t)(2 * x + pp) * stp.ip.inv_outer + (size_t)(stp.ip.inv_row0 + t - stp.ip.nl) * N + B0;
-        if (fp) p2_body<FpA, false, NP, 6>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
-        else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 6>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
-        else p2_body<IntA, false, NP, 6>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        if (fp) p2_body<FpA, false, NP, 6, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 6, SWZ>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        else p2_body<IntA, false, NP, 6, SWZ>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
         return;
     }
-    if (fp) p2_body<FpA, false, NP, 4>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
-    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 4>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
-    else p2_body<IntA, false, NP, 4>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+    if (fp) p2_body<FpA, false, NP, 4, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 4, SWZ>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+    else p2_body<IntA, false, NP, 4, SWZ>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
 }
 template <int NP, bool OWN, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
@@ -797,13 +810,14 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__r
 // each other; a tile is re-fetched once per group, from the Infinity Cache).
 template <int ND>
 __global__ __launch_bounds__(256) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int xb, NttStore stp) {
-    __shared__ u64 lds[ND][8 * 288];
+    constexpr bool SWZ = ND >= 3;  // three (or four) images: the unpadded, XOR-swizzled form buys a workgroup per CU (P2Lds)
+    __shared__ u64 lds[ND][P2Lds<SWZ>::SIZE];
     const int nl = stp.ip.nl, nS = stp.ip.nE, nP = nS - nl;
     const int per = nS * xb, grp = blockIdx.y / per, r = blockIdx.y - grp * per;
     const int si = r / xb, x = grp * xb + (r - si * xb);
     const int pc = si * nP / nS, pc1 = (si + 1) * nP / nS;
-    if (pc1 > pc) p2_ip_workgroup<ND, false, true>(T, dig, dxs, nl + pc, x, stp, blockIdx.x, lds);
-    else p2_ip_workgroup<ND - 1, true, false>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);
+    if (pc1 > pc) p2_ip_workgroup<ND, false, true, SWZ>(T, dig, dxs, nl + pc, x, stp, blockIdx.x, lds);
+    else p2_ip_workgroup<ND - 1, true, false, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);
 }
 
 
