@@ -142,19 +142,7 @@ struct ColFuse {
     u64 t60[HY_CF_TGT];                    // 2^60 mod q_tmod[t] (the FP64 fold of the conversion sums; filled by cf_plan_store)
 };
 
-// Resident database layouts.  Residues: limb 0 as 8-byte integers, (packed) limbs 1.. as 6-byte integers — or 8 bytes everywhere.
-//   ciphertext-major (seq = 0): ciphertext t at t*ct_bytes, polynomial p at + p*poly_bytes, limb j at + db_limb_offset(j), coefficients in order.
-//   group-sequential (seq = gs > 0), for databases of many blocks in the hoisted form: the bytes ONE loop-B workgroup reads — a
-//     128-coefficient tile of one limb of gs blocks (gs = waves x blocks per wave of the launch) — form ONE sequential run:
-//     [limb][tile][group of gs blocks][diagonal][block in group][polynomial][128 residues].  HBM serves that pattern at 7.0 TB/s
-//     where the ciphertext-major one (768-byte pieces 4.6 MB apart) gets 6.05 (tools/ubench/stream_rate.hip).
-// Both hold ct_bytes per ciphertext; a ciphertext's address is db_offset() in either.
-struct DbLayout {
-    unsigned long long ct_bytes, poly_bytes;
-    int packed;
-    int seq, seq_bpp;  // group size gs (0 = ciphertext-major) and the blocks per wave it was chosen with (waves = gs / seq_bpp)
-    int bd, blocks;    // seq: ciphertexts per block (the diagonal count), blocks resident
-};
+#include "db_layout.h"  // DbLayout, db_limb_offset, db_offset (host-checkable: tests/csrc/db_layout_check.cpp)
 
 // ---- device helpers shared by kernels.hip and ntt15.hip: 48-bit packed residues (database, rotation keys of loop A)
 #if defined(__HIPCC__)

@@ -542,16 +542,6 @@ __global__ __launch_bounds__(256) void k_rescale_combine(const ModC *__restrict_
 // grid (256 tiles * G/(NW*BPP), nl), block group fastest.
 // Database residues of the 45/46-bit limbs are stored as 48-bit integers (two per 12-byte load): -23 % HBM bytes on the
 // operand that dominates loop B.  Limb 0 (60 bit) and the rotated queries stay 8-byte.
-HD size_t db_limb_offset(const DbLayout &L, int N, int j) {
-    return L.packed ? (j == 0 ? 0 : (size_t)N * 8 + (size_t)(j - 1) * N * 6) : (size_t)j * N * 8;
-}
-// byte offset of residue c (even: residues travel in pairs) of limb j, polynomial p, ciphertext t
-HD size_t db_offset(const DbLayout &L, int N, size_t t, int p, int j, size_t c) {
-    const size_t es = (L.packed && j > 0) ? 6 : 8;
-    if (!L.seq) return t * L.ct_bytes + (size_t)p * L.poly_bytes + db_limb_offset(L, N, j) + c * es;
-    const size_t g = t / L.bd, i = t % L.bd, grp = g / L.seq, u = g % L.seq, tile = c >> 7, cc = c & 127, groups = L.blocks / L.seq;
-    return (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + ((((tile * groups + grp) * L.bd + i) * L.seq + u) * 2 + p) * 128 * es + cc * es;
-}
 // what a loop-B wave adds to its operand pointer: first byte of (block g0, diagonal 0, polynomial 0, its two residues) and the strides
 // to the next block of the wave, the next diagonal, the other polynomial.  g0 = first block of the wave, grp = its workgroup's group
 struct DbWalk {
