@@ -175,8 +175,9 @@ int hydia_db_import_ct(hydia_ctx *ctx, size_t t, const uint64_t *data /* [2][n_q
 int hydia_db_export_ct(hydia_ctx *ctx, size_t t, uint64_t *data);
 /* Persistence of the enrolled database (the reference keeps one serial/db_diagonal/index<t>.bin per ciphertext,
  * src/enroller/enroller_diag.cpp:158-166, and re-reads them every query; here the database stays in HBM and a file is only
- * what a server restart needs).  Own streaming format: a header (parameters, prime chain, packing) + the resident layout
- * verbatim; hydia_db_load refuses a file written for other parameters / primes / layout. */
+ * what a server restart needs).  Own streaming format: a header (parameters, prime chain, packing) + the ciphertexts in order, each
+ * as its packed residues (the ciphertext-major resident layout verbatim; a group-sequential database is converted on the way);
+ * hydia_db_load refuses a file written for other parameters / primes / residue width. */
 int hydia_db_save(hydia_ctx *ctx, const char *path);
 int hydia_db_load(hydia_ctx *ctx, const char *path);
 /* benchmark filler: n_vectors worth of uniformly random residues (the kernels' cost is data independent) */
