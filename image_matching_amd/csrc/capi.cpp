@@ -508,9 +508,8 @@ int hydia_db_set_babies(hydia_ctx *ctx, int babies) {
     Context &cx = ctx->cx;
     if (!cx.d_db || cx.db_cts == 0 || cx.db_kind == 4) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
     const int B = cx.babies_for(1, babies == cx.prm.dim ? 1 : babies);
-    if (cx.db_lay.seq && B != cx.db_lay.bd)
-        return fail(HYDIA_ERR_STATE, "hydia: this database lies group-sequentially for another form of the mat-vec; import a database of "
-                                     "this size whose form differs from the context's policy into a context created with HYDIA_DB_CT_MAJOR=1");
+    use_device(ctx);
+    cx.db_relayout(B);  // no-op unless the resident order was chosen for another form (hydia_db_alloc assumes the hoisted one)
     cx.db_babies = B;
     cx.db_kind = cx.db_babies < cx.prm.dim ? 6 : 5;
     return HYDIA_OK;

@@ -542,6 +542,31 @@ void Context::db_resize(size_t n_vectors, size_t cts, int form) {
                  ? hk::db_layout_seq(N, nQ, 1, form, (int)(cts / (size_t)form), tensor_bpp, tensor_nw)
                  : ctm;
 }
+// An imported database whose form is declared after the fact (hydia_db_set_babies): same ciphertexts, the order loop B wants for
+// that form.  Needs room for a second copy while it runs — the databases the split is meant for (a few dozen blocks) have it.
+void Context::db_relayout(int form) {
+    if (!d_db || db_cts == 0) return;
+    const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);
+    const DbLayout want = (db_seq_ok && db_packed && form >= 2 && db_cts % (size_t)form == 0)
+                              ? hk::db_layout_seq(N, nQ, 1, form, (int)(db_cts / (size_t)form), tensor_bpp, tensor_nw)
+                              : ctm;
+    if (want.seq == db_lay.seq && want.bd == db_lay.bd && want.seq_bpp == db_lay.seq_bpp) return;
+    sync_all();
+    unsigned char *fresh = nullptr;
+    HIP_CHECK(hipMalloc((void **)&fresh, db_cts * ctm.ct_bytes));
+    const size_t chunk = 16;
+    u64 *plain = pool.get(chunk * 2 * nQ * N * sizeof(u64));
+    for (size_t t0 = 0; t0 < db_cts; t0 += chunk) {
+        const int cnt = (int)std::min(chunk, db_cts - t0);
+        hk::db_unpack(stream, N, nQ, plain, d_db, t0, cnt, db_lay);
+        hk::db_pack(stream, N, nQ, plain, fresh, t0, cnt, want);
+    }
+    sync();
+    pool.put(plain);
+    HIP_CHECK(hipFree(d_db));
+    d_db = fresh;
+    db_lay = want;
+}
 namespace {
 struct DbFileHeader {
     char magic[8];  // "HYDIADB1"

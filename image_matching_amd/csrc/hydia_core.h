@@ -200,6 +200,7 @@ struct Context : HostParams {
     // for (vector_dim = the reference's form, or the baby count): loop B walks blocks of `form` ciphertexts, and more than 8 of them
     // take the group-sequential layout; -1 (HERS' column packing) stays ciphertext-major
     void db_resize(size_t n_vectors, size_t cts, int form);
+    void db_relayout(int form);  // the same ciphertexts laid out for another form (a second buffer for the duration)
     // persistence of the resident database (own streaming format: header + the ciphertext-major layout verbatim, so a restart does
     // not re-enrol from plaintext; the reference keeps serial/db_diagonal/index<t>.bin, enroller_diag.cpp:158-166)
     void db_save(const char *path);

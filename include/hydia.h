@@ -158,9 +158,8 @@ int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t se
  * to 3 blocks, 128 up to 12, 256 up to 24, hoisted above; measured, profiles/r03/matvec_sweep.txt), 1 hoisted, otherwise B itself; initial value from HYDIA_MATVEC=auto|hoisted|bsgs|<B>.
  * It takes effect at the NEXT enrolment; hydia_db_kind / hydia_db_babies tell what is resident (kind 0 none, 5 hoisted diagonals,
  * 6 pre-rotated diagonals, 4 HERS columns).  Ciphertexts imported one by one (hydia_db_alloc + hydia_db_import_ct: the reference
- * enroller's) are taken as hoisted unless hydia_db_set_babies says otherwise — which a database of more than 8 blocks accepts only
- * in a context created with HYDIA_DB_CT_MAJOR=1 (hydia_db_alloc has already laid it out group-sequentially for the hoisted form;
- * HYDIA_ERR_STATE otherwise, see hydia_db_group). */
+ * enroller's) are taken as hoisted unless hydia_db_set_babies says otherwise (a database of more than 8 blocks is then re-ordered in
+ * HBM for the declared form, through a second buffer of its size — see hydia_db_group). */
 int hydia_set_matvec(hydia_ctx *ctx, int mode);
 int hydia_get_matvec(const hydia_ctx *ctx);
 int hydia_db_kind(const hydia_ctx *ctx);

@@ -406,8 +406,13 @@ def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group
         want_idx = sender.indexScenario(gq).export()
         # (64-dimensional random rows cross the 0.44 threshold by chance now and then: the planted matches must be among the hits)
         assert {0, n // 2, n - 1} <= set(im.DiagonalReceiver(cc, n).decryptIndex(sender.indexScenario(gq)))
-        with pytest.raises(im.HydiaError):  # pre-rotated diagonals cannot be declared on a database laid out for the hoisted form
-            cc.db_set_babies(8)
+        # declaring another form re-orders the resident database (here: to blocks of 8 and back); the ciphertexts stay what they were
+        cc.db_set_babies(8)
+        assert cc.db_kind() == 6 and cc.db_group() > 0
+        assert np.array_equal(cc.db_export_ct(P.dim + 1), dbc[P.dim + 1].data())
+        cc.db_set_babies(P.dim)
+        assert cc.db_kind() == 5 and cc.db_group() == group
+        assert np.array_equal(sender.computeSimilarity(gq).export(), gs)
         path = str(tmp_path / "db.bin")
         cc.db_save(path)
         # ciphertext by ciphertext (the adapter's path), then the file, into the same context
