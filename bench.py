@@ -177,6 +177,81 @@ def git_head():
         return ""
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.  The children are plain
+    subprocesses of this interpreter (never os.exec*), started BEFORE this process has made any GPU or HIP call (it never makes
+    one), one per LOCAL_RANK, rendezvous on 127.0.0.1.  Rank 0's stdout is captured and its JSON line relayed; the other ranks'
+    stdout goes to stderr.  The first rank that fails takes the others down (by exact PID) and its exit code is returned."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HYDIA_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+    rc, out0 = 0, b""
+    try:
+        import threading
+        buf = []
+        rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        rd.start()
+        live = set(range(n))
+        while live and rc == 0:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0:
+                        rc = c if c > 0 else 128 - c
+                        sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
+                        break
+            time.sleep(0.05)
+        if rc:
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+        rd.join(timeout=30)
+        out0 = buf[0] if buf else b""
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 4
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def launcher_selftest(world, rank):
+    """--selftest-launcher: what a rank does when only the launch plumbing is to be exercised (CPU test of `--gpus N`): join the gloo
+    group the launcher described, all-reduce the ranks, rank 0 prints who came."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    fail = os.environ.get("HYDIA_BENCH_SELFTEST_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        sys.exit(7)  # before the barrier: the other ranks hang in it until the launcher stops them
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_initialised": dist.get_world_size(),
+                          "backend": dist.get_backend(), "rank_sum": float(t.item()),
+                          "self_launched": os.environ.get("HYDIA_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +268,21 @@ def main():
     ap.add_argument("--no-secondary-weak", action="store_true", help="N > 1: skip the weak-scaling figure of config.secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-db", action="store_true", help="fill the DB with random residues instead of enrolling")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # --gpus N is the contract: without a launcher around us (no WORLD_SIZE) we start the N ranks ourselves; under one
+    # (torch.distributed.run) its world size has to be the N that was asked for — a mismatch would silently measure another job
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to run a different job than asked\n"
+                         % (args.gpus, os.environ.get("WORLD_SIZE")))
+        sys.exit(2)
+    if args.selftest_launcher:
+        return launcher_selftest(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
 
     # stdout carries ONE line, the JSON result.  Native libraries write there too (RCCL prints a five-line version banner on fd 1 when
     # its first communicator comes up), so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
@@ -335,7 +424,22 @@ def main():
     if not args.random_db and rank == 0 and res is not None:
         correct = receiver.decryptIndex(res) == planted and len(res) == -(-n_total // S)
 
-    db_resident_bytes = cc.db_stats()[2]  # of the database that was timed (the optional weak figure below re-enrols)
+    # everything that describes the database that was TIMED is captured here: the optional weak figure below re-enrols on the same context
+    db_resident_bytes = cc.db_stats()[2]
+    db_kind_timed, db_babies_timed, db_group_timed = cc.db_kind(), cc.db_babies(), cc.db_group()
+    ranks_initialised = dist.get_world_size() if multi else 1
+    backend = dist.get_backend() if multi else None
+    # inherent bytes of the whole step (outside the timed region): one more query with the byte ledger on; the evaluator records what
+    # each OPERATION has to move as SURVEY 8d prices it ("op:*" entries: loop B's resident bytes, loop A's keys in + rotations out,
+    # 2 N 8 B per limb-transform of every relinearisation / rescale / rotation, each evaluation key once per launch, ct x ct operands)
+    step_ops = None
+    if rank == 0 or multi:
+        im.byte_ledger(1)
+        _r = sender.indexScenario(qc)
+        cc.sync()
+        led = im.byte_ledger(0)
+        del _r
+        step_ops = {k[3:]: v[1] for k, v in led.items() if k.startswith("op:")}
     if multi:  # every rank takes the same branches below (collectives inside)
         flag = [bool(correct)]
         dist.broadcast_object_list(flag, src=0)
@@ -367,10 +471,10 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         nl, N = cc.nQ, cc.N
-        bsgs = cc.db_kind() == 6
+        bsgs = db_kind_timed == 6
         # loop B's operands: the database once, the rotated queries once, the degree-2 accumulators once.  Hoisted form: dim rotated
         # queries, one accumulator per block; baby-step / giant-step form: B = 32 babies, dim / B accumulators per block
-        n_rot = cc.db_babies() if bsgs else dim
+        n_rot = db_babies_timed if bsgs else dim
         n_acc = G_local * (dim // n_rot if bsgs else 1)
         algo_bytes = (G_local * dim + n_rot) * 2 * nl * N * 8 + n_acc * 3 * nl * N * 8
         avg_launch_s = ms_tensor / max(launches, 1) / 1e3
@@ -394,11 +498,25 @@ def main():
             except Exception:
                 traffic = None
         db_gib = db_resident_bytes / 2 ** 30
+        # whole-step roofline: where the time outside loop B sits
+        step_roofline = None
+        if step_ops:
+            tot = sum(step_ops.values())
+            loop_b_b, loop_a_b = step_ops.get("loop_b", 0.0), step_ops.get("loop_a", 0.0)
+            step_roofline = {
+                "inherent_bytes": tot, "achieved": tot / (ms_step * 1e-3) / 1e9, "unit": "GB/s", "frac": tot / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms_per_step": ms_step, "ms_at_peak": tot / (HBM_PEAK_GBS * 1e9) * 1e3,
+                "bytes_by_operation": {k: round(v) for k, v in sorted(step_ops.items(), key=lambda kv: -kv[1])},
+                "ms_loop_b": avg_launch_s * 1e3, "ms_outside_loop_b": ms_step - avg_launch_s * 1e3,
+                "outside_loop_b": {"inherent_bytes": tot - loop_b_b, "frac": (tot - loop_b_b) / max((ms_step - avg_launch_s * 1e3) * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                                   "what": "loop A (keys in once, rotations out once: %.1f GB) + the per-block tails (relinearise, rescale, 22-product "
+                                           "comparator: 2 N 8 B per limb-transform, keys once per launch, ct x ct operands once)" % (loop_a_b / 1e9)}}
         out = {
             "metric": "encrypted DB vectors matched/sec (HyDia indexScenario, CKKS N=2^15)",
             "value": n_total * args.steps / elapsed,
             "unit": "vectors/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_initialised": ranks_initialised, "collective_backend": backend,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": (n_total * args.steps / elapsed) / PUBLISHED_2P20_INDEX_VPS if (world == 1 and n_total == 1 << 20) else None,
@@ -406,7 +524,7 @@ def main():
             "config": {"workload": workload_name(n_total, world, strong) + ": %d blocks of 16384 vectors on this GPU (%.0f GiB resident in "
                                    "HBM as 48-bit residues = %.0f GiB of 8-byte ciphertexts, %s), one query per step through indexScenario"
                                    % (G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30,
-                                      ("group-sequential layout, groups of %d blocks" % cc.db_group()) if cc.db_group() else "ciphertext-major layout"),
+                                      ("group-sequential layout, groups of %d blocks" % db_group_timed) if db_group_timed else "ciphertext-major layout"),
                        "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
                        "matvec": ("baby-step / giant-step: %d hoisted rotations of the query, %d relinearised partial sums per block rotated by "
@@ -423,21 +541,22 @@ def main():
                        "vs_baseline_note": "value / 10 864 vectors/s = the reference's published 2^20 index computation on a 48-thread Xeon "
                                            "(tools/figures/approach5.csv:12); null unless this run is that workload on one GPU",
                        "commit": git_head()},
-            "roofline": {"kernel": "k_hydia_tensor", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None, "traffic_meta": traffic_meta,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
-                         "wire": {"bytes_per_launch": resident_bytes, "achieved": wire, "frac": wire / HBM_PEAK_GBS,
-                                  "what": "resident-layout bytes (6-byte residues for the 45/46-bit limbs) / launch time: the rate HBM "
-                                          "actually has to sustain; against 7.05 TB/s, what this GPU gives a read-once sequential stream "
-                                          "(tools/ubench/stream_rate.hip, profiles/r03/stream_rate.txt; the guide's copy ceiling is 6.29), "
-                                          "this is %.2f" % (wire / 7050.0)},
-                         "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8d (196608 B per DB vector at 8 B per residue + rotated "
-                                 "queries + accumulators); one launch = loop B over all resident blocks (limb 0 and limbs 1-11 are two "
-                                 "kernels, timed together with HIP events on the library's stream).  The database holds the 45/46-bit "
-                                 "limbs as 6-byte residues, so frac can pass 1.0: `wire` is the same launch priced at the bytes resident "
-                                 "in HBM (the honest utilisation); `traffic` = PMC HBM bytes per launch (profiles/tensor_traffic.json), "
-                                 "quoted only while the kernel source it was profiled on is unchanged"},
+            "roofline": {"kernel": "k_hydia_tensor24 + k_hydia_tensor (loop B: limbs 1-11 and limb 0, timed together)", "bound": "hbm",
+                         "achieved": wire, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wire / HBM_PEAK_GBS,
+                         "bytes_per_launch": resident_bytes, "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
+                         "traffic": traffic, "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
+                         "traffic_meta": traffic_meta,
+                         "algorithmic_frac": achieved / HBM_PEAK_GBS, "algorithmic_achieved": achieved, "algorithmic_bytes_per_launch": algo_bytes,
+                         "vs_measured_stream_ceiling": wire / 7050.0,
+                         "step": step_roofline,
+                         "note": "achieved/frac = bytes RESIDENT in HBM that one loop-B pass has to move (database with 6-byte residues for the "
+                                 "45/46-bit limbs + rotated queries + accumulators at 8 bytes: every byte once) / mean pass duration (HIP events on "
+                                 "the library's stream) / 8 TB/s: a utilisation, <= 1.  algorithmic_* = the same pass priced by SURVEY 8d at 8 bytes "
+                                 "per residue (196608 B per DB vector): it exceeds `achieved` by the 6-byte storage and can pass 1.0 — a byte-saving "
+                                 "figure, not a utilisation.  vs_measured_stream_ceiling: against 7.05 TB/s, what this GPU gives a read-once sequential "
+                                 "stream (tools/ubench/stream_rate.hip; the guide's copy ceiling is 6.29).  traffic = PMC HBM bytes per launch "
+                                 "(profiles/tensor_traffic.json), quoted only while the kernel source it was profiled on is unchanged.  step = the whole "
+                                 "indexScenario: inherent bytes of every operation (byte ledger, op:* entries) / ms_per_step"},
         }
         if weak is not None:
             out["config"]["secondary"] = {"weak_scaling": weak}

@@ -19,6 +19,14 @@ namespace hydia {
 
 static u64 shoup_h(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
 
+// Inherent ("algorithmic") bytes of an OPERATION as SURVEY 8d prices them — 2 N 8 B (one read + one write) per limb-transform, an
+// evaluation key once per launch, operands of coefficient-wise work once — recorded in the byte ledger under "op:<name>" next to
+// the per-kernel entries (which count what the launches really move: a two-pass transform twice that).  bench.py's roofline.step
+// sums them over one indexScenario.  Costs nothing while the ledger is off.
+static void op_bytes(const char *op, size_t N, double transforms, double other_bytes) {
+    hk::ledger_add(op, transforms * 2.0 * (double)N * 8.0 + other_bytes);
+}
+
 void Context::ntt_fwd(u64 *base, size_t outer, int X, const LimbSel &s) {
     if (X <= 0 || s.n <= 0) return;
     hk::ntt_forward(stream, tabs, prm.logN, base, base, outer, outer, X, s);
@@ -446,6 +454,7 @@ void Context::relinearize(Ct &c, bool dbl) {
     if (c.npoly != 3) return;
     if (!relin_key.d) throw StateError("hydia: relinearisation key not loaded");
     const int nl = c.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X;
+    op_bytes("op:relinearize", N, (double)X * (nd * nE + 2 * nP + 2 * nl), (double)nd * 2 * nE * N * 8);
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, c.scale);
@@ -459,6 +468,7 @@ void Context::rescale(Ct &c, const Ct *sub, const double *addc) {
     const int nl = c.nl, l = nl - 1, XP = c.X * c.npoly;
     if (nl < 2) throw std::runtime_error("hydia: rescale with one limb left");
     if (sub && (sub->X != c.X || sub->npoly != c.npoly || sub->nl < l)) throw std::runtime_error("hydia: rescale sub operand shape");
+    op_bytes("op:rescale", N, (double)XP * nl, 0);
     u64 *t = pool.get((size_t)XP * N * sizeof(u64));
     const LimbSel last = sel_range(l, l + 1);
     ntt_inv(c.d + (size_t)l * N, t, c.poly_elems(), (size_t)N, XP, last, scale_ninv(last));
@@ -523,6 +533,8 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
 void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d) {
     const int nl = c.nl, l = nl - 1;
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
+    // relinearise (ModUp nd nE, ModDown 2 (nP + nl)) + rescale (2 nl) transforms per ciphertext: 80 + 24 at nl = 12
+    op_bytes("op:relin_rescale", N, (double)X * (nd * nE + 2 * nP + 4 * nl), (double)nd * 2 * nE * N * 8);
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     const u64 *c2 = c.d + 2 * c.poly_elems();
     // the inner product reads a digit's own limbs from c2, and (fuse_ip) consumes the ModUp transforms' second pass directly
@@ -634,10 +646,12 @@ static void check_same(const Ct &a, const Ct &b, const char *what) {
 }
 void Context::add_inplace(Ct &a, const Ct &b) {
     check_same(a, b, "add");
+    op_bytes("op:add", N, 0, 3.0 * a.X * a.npoly * a.nl * N * 8);
     hk::add(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride, b.lstride, a.lstride);
 }
 void Context::sub_inplace(Ct &a, const Ct &b) {
     check_same(a, b, "sub");
+    op_bytes("op:add", N, 0, 3.0 * a.X * a.npoly * a.nl * N * 8);
     hk::sub(stream, d_mod, N, a.d, b.d, a.d, a.X * a.npoly, sel_q(a.nl), a.lstride, b.lstride, a.lstride);
 }
 // EvalAddInPlace(ct, double) (openFHE_wrapper.cpp:182)
@@ -675,6 +689,7 @@ Ct Context::lincomb(const std::vector<const Ct *> &terms, const std::vector<doub
         }
     }
     for (int j = 0; j < f.nl; j++) lc.c0[j] = double_to_mod(c0 * S, q[j]);
+    op_bytes("op:lincomb", N, 0, (double)(lc.nterms + 1) * f.X * f.npoly * f.nl * N * 8);
     Ct o(this, f.X, f.npoly, f.nl, S);
     hk::lincomb(stream, d_mod, N, lc, o.d, f.X, f.npoly, f.nl);
     return o;
@@ -708,6 +723,7 @@ Ct Context::lincomb_multi(const std::vector<const Ct *> &terms, const std::vecto
     u64 *tab = pool.get(lcm_host.size() * sizeof(u64));
     HIP_CHECK(hipMemcpyAsync(tab, lcm_host.data(), lcm_host.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
     lc.tab = tab;
+    op_bytes("op:lincomb", N, 0, (double)(nt + K) * f.X * f.npoly * f.nl * N * 8);
     Ct o(this, f.X * K, f.npoly, f.nl, S[0]);
     hk::lincomb_multi(stream, d_mod, N, lc, o.d, f.X, f.npoly, f.nl);
     pool.put(tab);
@@ -716,6 +732,7 @@ Ct Context::lincomb_multi(const std::vector<const Ct *> &terms, const std::vecto
 // EvalMultNoRelin (sender_diag.cpp:93)
 Ct Context::mult_norelin(const Ct &a, const Ct &b) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
+    op_bytes("op:mult_norelin", N, 0, 7.0 * a.X * a.nl * N * 8);
     Ct o(this, a.X, 3, a.nl, a.scale * b.scale);
     hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl, a.lstride, b.lstride);
     return o;
@@ -725,6 +742,7 @@ Ct Context::mult_norelin(const Ct &a, const Ct &b) {
 Ct Context::mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2 || c.X != a.X || c.npoly != 2 || c.nl != a.nl)
         throw std::runtime_error("hydia: mult-sub shape mismatch");
+    op_bytes("op:mult_norelin", N, 0, 9.0 * a.X * a.nl * N * 8);
     Ct o(this, a.X, 3, a.nl, a.scale * b.scale);
     const u64 K = (u64)std::llround(o.scale / c.scale);
     ScaleSel kap{};
@@ -748,6 +766,7 @@ Ct Context::rotate(const Ct &a, int rot) {
     auto it = rot_keys.find(rot);
     if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(rot) + " not loaded");
     const int nl = a.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = a.X;
+    op_bytes("op:rotate", N, (double)X * (nd * nE + 2 * nP + 2 * nl), (double)nd * 2 * nE * N * 8 + 4.0 * X * nl * N * 8);
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(a.d + a.poly_elems(), a.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, a.scale);
@@ -779,6 +798,10 @@ void Context::rotate_query_range(const Ct &qc, int first, int count, u64 *out) {
     const int r0 = std::max(first, 1), nr = first + count - r0;
     if (nr <= 0) return;
     build_rotptrs();
+    // loop A as the review prices it: the shared ModUp, every rotation key in once (as resident: packed shadow or plain), every
+    // rotated ciphertext out once; the per-rotation ModDown transforms are NOT charged (13.9 GB at 511 rotations)
+    op_bytes("op:loop_a", N, (double)nd * nE,
+             (double)nr * (rotptrs_packed ? (double)hk::key_packed_bytes(N, nQ, nT, prm.dnum) : (double)nd * 2 * nE * N * 8) + (double)nr * 2 * nl * N * 8);
     u64 *dig = pool.get((size_t)nd * nE * N * sizeof(u64));
     modup_digits(qc.d + (size_t)nl * N, 0, 1, nl, dig);
     ks_apply(dig, 0, nr, nl, d_rotptrs + r0, 0, qc.d, 0, qc.poly_elems(), 1, d_rotgalois + r0, d_rotginv + r0, 0, false,
@@ -860,6 +883,7 @@ Ct Context::similarity_bsgs_sum(const Ct &qc) {
     // inner sums: ciphertext t = (block*NG + g)*B + b is "diagonal b of block block*NG + g"; the accumulators come out giant-major
     // (slot g*G + block), so every later step is ONE batch over all database blocks
     Ct acc(this, G * NG, 3, nl, qc.scale * delta);
+    op_bytes("op:loop_b", N, 0, (double)db_cts * (double)db_layout().ct_bytes + ((double)B * 2 + (double)G * NG * 3) * nl * N * 8);
     timer_begin("hydia_tensor");
     hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G * NG, B, nl, tensor_bpp, tensor_nw, db_lay, NG);
     timer_end("hydia_tensor");
@@ -870,6 +894,7 @@ Ct Context::similarity_bsgs_sum(const Ct &qc) {
     if (NG > 1) {
         const int X = (NG - 1) * G;
         const size_t ce = acc.ct_elems();
+        op_bytes("op:rotate", N, (double)X * (nd * nE + 2 * nP + 2 * nl), (double)(NG - 1) * nd * 2 * nE * N * 8 + 4.0 * X * nl * N * 8);
         Ct rotd(this, X, 2, nl, acc.scale);
         u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
         const u64 *c = acc.d + (size_t)G * ce;
@@ -878,6 +903,7 @@ Ct Context::similarity_bsgs_sum(const Ct &qc) {
         pool.put(dig);
         HIP_CHECK(hipMemcpyAsync(acc.d + (size_t)G * ce, rotd.d, (size_t)X * ce * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     }
+    op_bytes("op:add", N, 0, (double)(NG + 1) * G * 2 * nl * N * 8);
     hk::batch_sum(stream, d_mod, N, acc.d, out.d, NG, 2, nl, G, G);
     return out;
 }
@@ -1231,6 +1257,7 @@ Ct Context::similarity_accumulate_rot(const Ct &rot) {
         throw StateError("hydia: rotations must be vector_dim fresh 2-component ciphertexts");
     const int G = (int)(db_cts / dim);
     Ct acc(this, G, 3, nQ, rot.scale * delta);
+    op_bytes("op:loop_b", N, 0, (double)db_cts * (double)db_layout().ct_bytes + ((double)dim * 2 + (double)G * 3) * nQ * N * 8);
     timer_begin("hydia_tensor");
     hk::hydia_tensor_accumulate(stream, d_mod, N, rot.d, d_db, acc.d, G, dim, nQ, tensor_bpp, tensor_nw, db_lay);
     timer_end("hydia_tensor");

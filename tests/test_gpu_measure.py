@@ -44,3 +44,55 @@ def test_ntt_microbenchmark_entry_point():
     with pytest.raises(im.HydiaError):
         cc.bench_ntt(1, 15, 4, False, 1)              # moduli out of range
     cc.close()
+
+
+def test_op_ledger_prices_a_relinearisation_like_the_survey():
+    """bench.py's roofline.step sums the ledger's op:* entries: SURVEY 8d's prices (relinearise 80 + rescale 24 limb-transforms of
+    2 N 8 B at 12 limbs + the 24 MiB key; loop B = resident database + rotated queries + accumulators)"""
+    import image_matching_amd as im
+    cc = im.Context()
+    cc.fill_eval_keys_random(1)
+    n = 16384
+    cc.set_matvec("hoisted")  # the reference's form: 511 hoisted rotations, one relinearisation per block
+    cc.db_fill_random(n, 2)
+    rng = np.random.default_rng(0)
+    q = np.stack([rng.integers(0, int(m), size=(2, cc.N), dtype=np.uint64) for m in cc.moduli[:cc.nQ]], axis=1)
+    gq = cc.import_ct(q, cc.delta)
+    sender = im.DiagonalSender(cc, n)
+    sender.computeSimilarity(gq)
+    im.byte_ledger(1)
+    sender.computeSimilarity(gq)
+    cc.sync()
+    led = im.byte_ledger(0)
+    ops = {k: v for k, v in led.items() if k.startswith("op:")}
+    lp = cc.N * 8
+    assert cc.db_kind() == 5
+    assert ops["op:relin_rescale"] == (1, (80 + 24) * 2 * lp + 3 * 2 * 16 * lp)
+    assert ops["op:loop_b"][1] == cc.db_stats()[2] + (512 * 2 + 3) * 12 * lp
+    assert abs(ops["op:loop_a"][1] - 13.9e9) < 0.6e9  # the review's figure for loop A: keys in once, rotations out once
+    assert all(v[1] > 0 for v in ops.values())
+    del gq
+    cc.close()
+
+
+def test_bench_gpus_flag_runs_two_real_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself.  Rehearsal mode (both ranks compute on GPU 0,
+    collectives over gloo) is the only way to run world 2 on a one-GPU box; the line must say how many ranks really joined."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HYDIA_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-log2n", "15", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary-weak"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_initialised"] == 2 and out["collective_backend"] == "gloo"
+    assert out["config"]["result_correct"] is True and out["scaling"] == "strong"
+    rf = out["roofline"]
+    assert 0 < rf["frac"] <= 1.0 and rf["algorithmic_frac"] >= rf["frac"]
+    assert rf["step"]["inherent_bytes"] > rf["bytes_per_launch"] and 0 < rf["step"]["frac"] < rf["frac"] + 1e-9

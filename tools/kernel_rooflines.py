@@ -43,3 +43,7 @@ for k, n, ms, b in sorted(rows, key=lambda r: -r[2]):
     print("%-40s %6d %9.3f %10.3f %8.2f" % (k[:40], n, ms, b / 1e9, b / ms / 1e9 if ms else 0))
 for k, c, m in other:
     print("%-40s %6d %9.3f %10s %8s   (not in the ledger: %d calls in the whole profile)" % (k[:40], c // (Q + 1), m / (Q + 1), "-", "-", c))
+ops = {k[3:]: v["bytes"] / Q for k, v in led["ledger"].items() if k.startswith("op:")}
+if ops:
+    print("inherent bytes per query by operation (SURVEY 8d pricing: 2 N 8 B per limb-transform, keys once per launch): %.1f GB in all — %s"
+          % (sum(ops.values()) / 1e9, ", ".join("%s %.2f" % (k, b / 1e9) for k, b in sorted(ops.items(), key=lambda kv: -kv[1]))))
