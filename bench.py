@@ -330,7 +330,9 @@ def main():
     t0 = time.time()
     if args.random_db:
         if n_local:
+            cc.set_matvec(im.group_babies(cc, n_total, world) if world > 1 else "auto")  # ONE split for every shard: the group-wide rule
             cc.db_fill_random(n_local, SEED + rank)
+            cc.set_matvec("auto")
     else:
         rows = synth_rows(first, last, dim, planted)
         im.DistDiagonalEnroller(cc, n_total, rank, world).serializeDB(rows, seed=SEED + 7)

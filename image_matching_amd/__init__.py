@@ -14,7 +14,7 @@ from .hydia import (Context, Ciphertext, DiagonalEnroller, DiagonalReceiver, Dia
                     HersEnroller, HersReceiver, HersSender,
                     byte_ledger, default_params, describe_params, compute_required_depth, lib_path, load_library)
 from .sharding import (ShardGroup, ShardedDiagonalEnroller, ShardedDiagonalSender, DistDiagonalEnroller,  # noqa: F401
-                       DistDiagonalSender, shard_blocks, shard_vectors)
+                       DistDiagonalSender, group_babies, shard_blocks, shard_vectors)
 
 MATCH_THRESHOLD = 0.44  # include/config.h:9
 COMP_DEPTH = 10         # include/config.h:14

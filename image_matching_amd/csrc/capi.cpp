@@ -95,7 +95,9 @@ int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
-    REQUIRE(device >= 0 && device < ndev, "bad device index");
+    REQUIRE(device >= 0, "bad device index");
+    if (device >= ndev)  // a device this machine does not have (a shard list written for a bigger node): a device error, not a typo
+        return fail(HYDIA_ERR_DEVICE, "hydia: device index " + std::to_string(device) + " but only " + std::to_string(ndev) + " HIP device(s) visible");
     *out = new hydia_ctx(hydia_to_params(p), device);
     return HYDIA_OK;
     API_END
@@ -108,7 +110,9 @@ int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
-    REQUIRE(device >= 0 && device < ndev, "bad device index");
+    REQUIRE(device >= 0, "bad device index");
+    if (device >= ndev)  // a device this machine does not have (a shard list written for a bigger node): a device error, not a typo
+        return fail(HYDIA_ERR_DEVICE, "hydia: device index " + std::to_string(device) + " but only " + std::to_string(ndev) + " HIP device(s) visible");
     Params prm = hydia_to_params(p);
     prm.mult_depth = (int)n_q - 1;
     prm.custom_q.assign(moduli, moduli + n_q + n_p);
@@ -506,8 +510,13 @@ int hydia_db_set_babies(hydia_ctx *ctx, int babies) {
     API_BEGIN
     REQUIRE(ctx, "null argument");
     Context &cx = ctx->cx;
-    if (!cx.d_db || cx.db_cts == 0 || cx.db_kind == 4) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
-    const int B = cx.babies_for(1, babies == cx.prm.dim ? 1 : babies);
+    if (!cx.d_db || cx.db_cts == 0 || (cx.db_kind != 5 && cx.db_kind != 6)) return fail(HYDIA_ERR_STATE, "hydia: no diagonal database resident");
+    // a DECLARED form: vector_dim (hoisted) or a power of two >= 2 dividing it — never 0 / 1, which mean "auto" / "hoisted" only in
+    // hydia_set_matvec's policy and would silently mark an imported hoisted database as pre-rotated
+    const int dim = cx.prm.dim;
+    REQUIRE(babies == dim || (babies >= 2 && babies < dim && (babies & (babies - 1)) == 0 && dim % babies == 0),
+            "the declared baby count must be vector_dim or a power of two >= 2 dividing it");
+    const int B = babies;
     use_device(ctx);
     cx.db_relayout(B);  // no-op unless the resident order was chosen for another form (hydia_db_alloc assumes the hoisted one)
     cx.db_babies = B;
@@ -579,6 +588,7 @@ int hydia_rotate_query_range_into(hydia_ctx *ctx, const hydia_ct *query, uint32_
     API_BEGIN
     use_device(ctx);
     REQUIRE(ctx && query && dev_dst, "null argument");
+    REQUIRE(first <= (uint32_t)ctx->cx.prm.dim && count <= (uint32_t)ctx->cx.prm.dim - first, "rotation range outside 0 .. vector_dim");
     ctx->cx.rotate_query_range(query->c, (int)first, (int)count, static_cast<u64 *>(dev_dst));
     return HYDIA_OK;
     API_END
@@ -587,6 +597,8 @@ int hydia_rotate_query_range(hydia_ctx *ctx, const hydia_ct *query, uint32_t fir
     API_BEGIN
     use_device(ctx);
     REQUIRE(ctx && query && out && count >= 1, "bad argument");
+    // validated on the unsigned values BEFORE anything is allocated (first + count must not wrap)
+    REQUIRE(first <= (uint32_t)ctx->cx.prm.dim && count <= (uint32_t)ctx->cx.prm.dim - first, "rotation range outside 0 .. vector_dim");
     Ct r(&ctx->cx, (int)count, 2, query->c.nl, query->c.scale);
     ctx->cx.rotate_query_range(query->c, (int)first, (int)count, r.d);
     *out = wrap(ctx, std::move(r));

@@ -107,6 +107,7 @@ u64 double_to_mod(double v, u64 q) {
 // ------------------------------------------------------------------ pool
 Pool::~Pool() { trim(); }
 u64 *Pool::get(size_t bytes) {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     bytes = (bytes + 255) & ~(size_t)255;
     auto &fl = free_[cur];
     auto it = fl.lower_bound(bytes);
@@ -130,6 +131,7 @@ u64 *Pool::get(size_t bytes) {
 }
 void Pool::put(u64 *p) {
     if (!p) return;
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     auto it = size_.find(p);
     if (it == size_.end()) return;
     free_[it->second.second].emplace(it->second.first, p);  // back to the lane that owns it
@@ -138,6 +140,7 @@ void Pool::put(u64 *p) {
     size_.erase(it);
 }
 void Pool::trim() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     for (auto &fl : free_)
         for (auto &kv : fl.second) (void)hipFree(kv.second);
     free_.clear();
@@ -543,7 +546,9 @@ void Context::db_resize(size_t n_vectors, size_t cts, int form) {
                  : ctm;
 }
 // An imported database whose form is declared after the fact (hydia_db_set_babies): same ciphertexts, the order loop B wants for
-// that form.  Needs room for a second copy while it runs — the databases the split is meant for (a few dozen blocks) have it.
+// that form.  Needs room for a second copy while it runs — the databases the split is meant for (a few dozen blocks) have it; when
+// the second buffer does not fit (a 148 GiB database on a 288 GB GPU) the call fails with a DeviceError BEFORE anything is touched:
+// the resident database, its layout and its declared form stay what they were.
 void Context::db_relayout(int form) {
     if (!d_db || db_cts == 0) return;
     const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);
@@ -552,19 +557,38 @@ void Context::db_relayout(int form) {
                               : ctm;
     if (want.seq == db_lay.seq && want.bd == db_lay.bd && want.seq_bpp == db_lay.seq_bpp) return;
     sync_all();
-    unsigned char *fresh = nullptr;
-    HIP_CHECK(hipMalloc((void **)&fresh, db_cts * ctm.ct_bytes));
+    struct Scratch {  // whatever throws below, neither buffer leaks and the resident database is still the old one
+        Context *c;
+        unsigned char *fresh = nullptr;
+        u64 *plain = nullptr;
+        ~Scratch() {
+            if (plain) c->pool.put(plain);
+            if (fresh) (void)hipFree(fresh);
+        }
+    } s{this};
+    const size_t bytes = db_cts * ctm.ct_bytes;
+    hipError_t e = hipMalloc((void **)&s.fresh, bytes);
+    if (e != hipSuccess) {
+        pool.trim();  // cached evaluator temporaries may be what stands in the way
+        (void)hipGetLastError();
+        e = hipMalloc((void **)&s.fresh, bytes);
+    }
+    if (e != hipSuccess) {
+        s.fresh = nullptr;
+        (void)hipGetLastError();
+        throw DeviceError("hydia: re-ordering the resident database for another mat-vec form needs a second buffer of " +
+                          std::to_string(bytes >> 20) + " MiB, which does not fit in device memory (" + hipGetErrorString(e) +
+                          "); the database is unchanged — enrol or load it with the form set beforehand (hydia_set_matvec)");
+    }
     const size_t chunk = 16;
-    u64 *plain = pool.get(chunk * 2 * nQ * N * sizeof(u64));
+    s.plain = pool.get(chunk * 2 * nQ * N * sizeof(u64));
     for (size_t t0 = 0; t0 < db_cts; t0 += chunk) {
         const int cnt = (int)std::min(chunk, db_cts - t0);
-        hk::db_unpack(stream, N, nQ, plain, d_db, t0, cnt, db_lay);
-        hk::db_pack(stream, N, nQ, plain, fresh, t0, cnt, want);
+        hk::db_unpack(stream, N, nQ, s.plain, d_db, t0, cnt, db_lay);
+        hk::db_pack(stream, N, nQ, s.plain, s.fresh, t0, cnt, want);
     }
     sync();
-    pool.put(plain);
-    HIP_CHECK(hipFree(d_db));
-    d_db = fresh;
+    std::swap(d_db, s.fresh);  // the old buffer leaves with the scratch object
     db_lay = want;
 }
 namespace {

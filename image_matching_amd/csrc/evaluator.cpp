@@ -790,7 +790,7 @@ Ct Context::rotate_query(const Ct &qc) {
 void Context::rotate_query_range(const Ct &qc, int first, int count, u64 *out) {
     if (qc.X != 1 || qc.npoly != 2 || !qc.compact()) throw std::runtime_error("hydia: query must be one 2-component ciphertext");
     const int dim = prm.dim;
-    if (first < 0 || count < 0 || first + count > dim) throw std::runtime_error("hydia: rotation range outside 0 .. vector_dim");
+    if (first < 0 || count < 0 || first > dim || count > dim - first) throw std::runtime_error("hydia: rotation range outside 0 .. vector_dim");
     if (count == 0) return;
     const int nl = qc.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const size_t ce = qc.ct_elems();

@@ -202,8 +202,12 @@ int hydia_group_create(const hydia_params *p, const int *devices, uint32_t n_sha
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
             return hydia_fail(HYDIA_ERR_DEVICE, "hydia: no HIP device visible — libhydia has no CPU fallback");
-        for (uint32_t r = 0; r < n_shards; r++)
-            if (devices[r] < 0 || devices[r] >= ndev) return hydia_fail(HYDIA_ERR_ARG, "bad device index");
+        for (uint32_t r = 0; r < n_shards; r++) {
+            if (devices[r] < 0) return hydia_fail(HYDIA_ERR_ARG, "bad device index");
+            if (devices[r] >= ndev)  // a shard list written for a bigger node: nothing is created, nothing leaks
+                return hydia_fail(HYDIA_ERR_DEVICE, ("hydia: shard " + std::to_string(r) + " asks for device " + std::to_string(devices[r]) + " but only " +
+                                                     std::to_string(ndev) + " HIP device(s) visible"));
+        }
         g = new hydia_group;
         for (uint32_t r = 0; r < n_shards; r++) g->shard.push_back(new hydia_ctx(hydia_to_params(p), devices[r]));
         g->blk_lo.assign(n_shards, 0);

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -53,6 +54,9 @@ class Pool {
     int cur = 0;
 
   private:
+    // handles may be freed from another thread than the one inside a library call (a garbage collector's finaliser while ctypes has
+    // released the GIL): the free lists are guarded; `cur` is only changed by the thread that owns the context
+    std::recursive_mutex mu_;
     std::map<int, std::multimap<size_t, u64 *>> free_;    // per lane
     std::map<u64 *, std::pair<size_t, int>> size_;         // block -> (bytes, owning lane)
 };

@@ -154,6 +154,11 @@ class DistDiagonalSender:
         self.cc, self.n_total, self.dist, self.rank, self.world, self.staging = cc, n_total, dist, rank, world, staging
         if world > 16:  # the membership reduction adds residues below 2^60 as 64-bit integers: exact for at most 16 terms
             raise ValueError("DistDiagonalSender supports at most 16 ranks (integer sum of partial membership ciphertexts)")
+        # RCCL wants one GPU per rank (it refuses two ranks on one device, and then only deep inside the first collective): say so here
+        backend = getattr(dist, "get_backend", lambda: None)() if world > 1 else None
+        if staging == "device" and backend == "nccl" and torch.cuda.device_count() < world:
+            raise RuntimeError("DistDiagonalSender over RCCL needs one GPU per rank: world size %d but %d GPU(s) visible on this node "
+                               "(use fewer ranks, or staging='host' over gloo to rehearse on one GPU)" % (world, torch.cuda.device_count()))
         self.G = -(-n_total // cc.slots)
         self.ranges = [shard_blocks(self.G, world, r) for r in range(world)]
         self.lo, self.hi = self.ranges[rank]
@@ -166,11 +171,45 @@ class DistDiagonalSender:
         # over xGMI), so the node does loop A's work once instead of once per GPU.  Same ciphertexts either way.
         self.active = [r for r, (lo, hi) in enumerate(self.ranges) if hi > lo]
         K = len(self.active)
-        # the baby-step / giant-step form needs B - 1 rotations per query: nothing worth sharing out
-        self.bsgs = hasattr(cc, "auto_babies") and group_babies(cc, n_total, world) < cc.dim
-        self.rotation_split = bool(rotation_split) and world > 1 and K > 1 and not self.bsgs
+        # The form of the mat-vec is read off the RESIDENT databases (kind 5 hoisted / kind 6 pre-rotated with B babies), not re-derived
+        # from the policy: a database that was loaded from a file, enrolled with an explicit split or filled per rank need not be what
+        # the policy would pick today.  The ranks that hold blocks must agree (one split serves every shard of a database); the
+        # baby-step / giant-step form needs B - 1 rotations per query — nothing worth sharing out, and the *Rotated entry points take
+        # hoisted databases only — so option B is refused there.
+        self._want_split = bool(rotation_split) and world > 1 and K > 1
+        self.bsgs, self.babies, self._form = False, None, None
+        self.rotation_split = self._want_split
+        self._agree_form()
         self.rot_ranges = {r: shard_blocks(cc.dim, K, k) for k, r in enumerate(self.active)}
         self.rot_even = K > 0 and cc.dim % K == 0 and K == world  # every rank holds blocks and the ranges are equal: in-place all_gather
+
+    def _local_form(self):
+        cc = self.cc
+        if self.local is None or not hasattr(cc, "db_kind"):
+            return None
+        return (int(cc.db_kind()), int(cc.db_babies()))
+
+    def _agree_form(self):
+        """(collective) every rank's resident (kind, babies); the block-holding ranks must hold ONE form.  Run at construction and
+        again by the first scenario call after the local database changed (every rank re-enrols together or not at all)."""
+        mine = self._local_form()
+        forms = [mine]
+        if self.world > 1 and hasattr(self.cc, "db_kind"):
+            forms = [None] * self.world
+            self.dist.all_gather_object(forms, mine)
+        self._form = mine
+        held = sorted({f for f in forms if f is not None and f[0] != 0})
+        if len(held) > 1:
+            raise ValueError("DistDiagonalSender: the ranks hold databases of different mat-vec forms (kind, babies) = %s; enrol every "
+                             "shard with the group-wide split (sharding.group_babies)" % (held,))
+        if held and held[0][0] not in (5, 6):
+            raise ValueError("DistDiagonalSender needs a diagonal (approach 5) database, found kind %d" % held[0][0])
+        if held:
+            self.bsgs, self.babies = held[0][0] == 6, held[0][1]
+        elif hasattr(self.cc, "auto_babies"):  # nothing enrolled yet: what the policy will pick (checked again at the first call)
+            self.babies = group_babies(self.cc, self.n_total, self.world)
+            self.bsgs = self.babies < self.cc.dim
+        self.rotation_split = self.rotation_split and self._want_split and not self.bsgs
 
     # ---- buffers: int64 tensors that mirror [count][poly][limb][N] residues
     def _buf(self, key, n):
@@ -284,6 +323,11 @@ class DistDiagonalSender:
         return cc.import_ct(full.numpy().view(np.uint64).reshape(dim, 2, cc.nQ, cc.N), scale)
 
     def _local(self, fn_name, q):
+        if self._local_form() != self._form:  # re-enrolled, loaded or re-declared since the ranks last agreed
+            self._agree_form()
+        if self.rotation_split and self.bsgs:
+            raise ValueError("rotation_split (loop A shared out over the ranks) needs hoisted databases; the resident ones are pre-rotated "
+                             "for %s babies" % self.babies)
         if self.rotation_split and not self.bsgs and len(self.active) > 1:
             rot = self._gathered_rotations(q)
             return getattr(self.local, fn_name + "Rotated")(rot) if self.local is not None else None

@@ -120,6 +120,74 @@ def test_three_block_sender_bit_exact_full_ring(im, full, matvec):
     assert receiver.decryptMembership(gmem) is True
 
 
+@pytest.mark.parametrize("blocks,matvec,babies,group,checks", [(4, None, 128, 0, "sim idx mem"), (13, None, 256, 8, "idx"),
+                                                               (9, "hoisted", 512, 8, "sim")])
+def test_auto_tiers_and_headline_kernel_bit_exact_full_ring(im, full, blocks, matvec, babies, group, checks):
+    """Round-3 review: the auto rule's 128-baby (4-12 blocks: what BASELINE config 4's database and every 8-block shard of config 5
+    get) and 256-baby (13-24 blocks) splits were compared with the oracle nowhere, and the headline loop-B kernel (k_hydia_tensor24 on
+    the group-sequential layout, hoisted databases of more than 8 blocks) only at N = 2^11.  Here at N = 2^15 / dim 512 on ragged
+    databases: similarity, index and membership ciphertexts equal the oracle's restatement of the same split, bit for bit."""
+    P, K, Or, cc = full
+    n = blocks * P.slots - 5
+    rng = np.random.default_rng(1000 + blocks)
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.int8).astype(np.float64)
+    planted = [3, n // 2, n - 1]
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    query = np.ones(512)
+    cc.set_matvec("auto" if matvec is None else matvec)
+    try:
+        dbc = Or.enroll(db.copy(), 8, matvec=matvec)
+        assert dbc.babies == babies == (O.auto_babies(512, blocks) if matvec is None else 512)
+        im.DiagonalEnroller(cc, n).serializeDB(db, seed=8)
+    finally:
+        cc.set_matvec("auto")
+    del db
+    assert cc.db_babies() == babies and cc.db_kind() == (5 if babies == 512 else 6) and cc.db_group() == group
+    for t in (0, 511, 512 * (blocks - 1) + 130, 512 * blocks - 1):
+        assert np.array_equal(cc.db_export_ct(t), dbc[t].data()), t
+    q = Or.encrypt_query(query, 2, 9)
+    receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+    gq = receiver.encryptQuery(query, seed=2, nonce=9)
+    # (the oracle runs on the box's 16 cores: each case takes the checks that are new for it — index = similarity + comparator)
+    if "sim" in checks:
+        sim = Or.compute_similarity(q, dbc, n)
+        gs = sender.computeSimilarity(gq).export()
+        assert len(sim) == blocks
+        for g in range(blocks):
+            assert np.array_equal(gs[g], sim[g].data()), g
+        del sim, gs
+    if "idx" in checks:
+        idx, gidx = Or.index_scenario(q, dbc, n), sender.indexScenario(gq)
+        gi = gidx.export()
+        for g in range(blocks):
+            assert np.array_equal(gi[g], idx[g].data()), g
+        assert receiver.decryptIndex(gidx) == planted == Or.decrypt_index(idx)
+        del idx, gidx
+    else:
+        assert receiver.decryptIndex(sender.indexScenario(gq)) == planted
+    if "mem" in checks:
+        mem, gmem = Or.membership_scenario(q, dbc, n), sender.membershipScenario(gq)
+        assert np.array_equal(gmem.export()[0], mem.data()) and receiver.decryptMembership(gmem) is True
+    del dbc, gq
+    cc.db_alloc(1)  # give the HBM back to the tests that follow
+
+
+@pytest.mark.parametrize("blocks,pick", [(16, 1), (24, 1), (8, 1), (16, 0)])
+def test_loop_b_against_host_recomputation_full_ring(blocks, pick):
+    """The headline kernel directly: loop B as a query runs it (Context::similarity_accumulate_rot) at N = 2^15, dim = 512 — the
+    24-bit-halves kernel on the group-sequential layout (16 and 24 blocks), the 128-bit kernel on ciphertext-major databases (8
+    blocks; 16 with the layout forced) — against unsigned __int128 on the host: 0 mismatches over every (block, limb, coefficient).
+    tests/csrc/loop_b_check.cpp, built by __graft_entry__.build(); this is the check that found ROCm 7.2's miscompile of that kernel."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "loop_b_check")
+    assert os.path.exists(exe), "tests/csrc/loop_b_check is built by __graft_entry__.build()"
+    r = subprocess.run([exe, str(blocks), "512", "15", str(pick)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("group-sequential" if (pick and blocks > 8) else "ciphertext-major") in r.stdout
+    assert " 0 mismatches of %d " % (blocks * 12 * 32768) in r.stdout
+
+
 def test_config3_one_full_block_bit_exact_full_ring(im, full):
     """BASELINE config 3 in its stated form: n = 16384 exactly (one FULL block, all 32 sub-blocks of every ciphertext populated):
     similarity, index and membership ciphertexts equal the oracle's; answers = the planted matches, incl. the last slot."""

@@ -543,3 +543,33 @@ def test_shard_group_full_size_2p20(im):
     assert gr.decryptMembership(gs.membershipScenario(gq)) is True
     del gq, gidx
     grp.close()
+
+
+def test_more_shards_or_ranks_than_gpus_fail_with_a_clear_error(im):
+    """Failure handling that needs no second GPU to test (round-3 review): a shard list naming a device this node does not have is a
+    DEVICE error from hydia_group_create / hydia_ctx_create (nothing is created); DistDiagonalSender over RCCL with more ranks than
+    GPUs says so at construction instead of failing deep inside the first collective."""
+    import torch
+    ndev = torch.cuda.device_count()
+    with pytest.raises(im.HydiaError) as e:
+        im.ShardGroup([0, ndev], im.default_params(log_n=11, vector_dim=64))
+    assert e.value.code == -3 and "only %d HIP device" % ndev in str(e.value)
+    with pytest.raises(im.HydiaError) as e:
+        im.Context(im.default_params(log_n=11, vector_dim=64), ndev + 3)
+    assert e.value.code == -3
+    with pytest.raises(im.HydiaError) as e:
+        im.Context(im.default_params(log_n=11, vector_dim=64), -1)
+    assert e.value.code == -1
+
+    class NcclLike:  # only what the constructor asks before it refuses
+        @staticmethod
+        def get_backend():
+            return "nccl"
+
+    cc = im.Context(im.default_params(log_n=11, vector_dim=64), 0)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            im.DistDiagonalSender(cc, 5000, NcclLike, 0, ndev + 1, staging="device")
+        assert "one GPU per rank" in str(e.value) and "%d GPU" % ndev in str(e.value)
+    finally:
+        cc.close()
