@@ -143,6 +143,10 @@ DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 #pragma unroll
         for (int k = 0; k < 16; k++)
             if (!(k & h)) ar.ct(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
+        if (st == 2) {  // lazy 60-bit limbs: three stages between folds (ntt_arith.h)
+#pragma unroll
+            for (int k = 0; k < 16; k++) ar.fwd_fold(v[k]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[(g + 8 * k) * 32 + col] = A::to_bits(v[k]);
@@ -161,6 +165,8 @@ DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 #pragma unroll
         for (int l = 0; l < 8; l++)
             if (!(l & 2)) ar.ct(w[l], w[l + 2], A::tw(ltw[32 + 2 * h + (l >> 2)]));
+#pragma unroll
+        for (int l = 0; l < 8; l++) ar.fwd_fold(w[l]);
 #pragma unroll
         for (int l = 0; l < 8; l += 2) ar.ct(w[l], w[l + 1], A::tw(ltw[64 + 4 * h + (l >> 1)]));
 #pragma unroll

@@ -72,6 +72,10 @@ DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u6
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (!(k & h)) ar.ct(v[k], v[k + h], A::tw(tw[(1 << st) + (k >> (4 - st))]));
+            if (st == 2) {  // lazy 60-bit limbs: three stages between folds
+#pragma unroll
+                for (int k = 0; k < 16; k++) ar.fwd_fold(v[k]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[(g + 8 * k) * 32 + col] = A::to_bits(v[k]);
@@ -90,6 +94,8 @@ DEV void p1_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *s, u6
 #pragma unroll
             for (int l = 0; l < 8; l++)
                 if (!(l & 2)) ar.ct(w[l], w[l + 2], A::tw(ltw[32 + 2 * h + (l >> 2)]));
+#pragma unroll
+            for (int l = 0; l < 8; l++) ar.fwd_fold(w[l]);
 #pragma unroll
             for (int l = 0; l < 8; l += 2) ar.ct(w[l], w[l + 1], A::tw(ltw[64 + 4 * h + (l >> 1)]));
 #pragma unroll
@@ -564,7 +570,10 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) ar.ct(v[p][k], v[p][k + 1], W9[k >> 1]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) lds[p][LI::at(blk, k, w)] = A::to_bits(v[p][k]);
+                for (int k = 0; k < 8; k++) {
+                    ar.fwd_fold(v[p][k]);
+                    lds[p][LI::at(blk, k, w)] = A::to_bits(v[p][k]);
+                }
             }
         }
         __syncthreads();

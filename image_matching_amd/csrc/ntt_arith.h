@@ -2,7 +2,8 @@
 //
 // Chosen per limb (workgroup-uniform) and all EXACT, so results are bit-identical:
 //   IntA  64-bit integers, Shoup multiplication, Harvey lazy reduction ([0,4q) forward, [0,2q) inverse): any prime up to 61 bits.
-//   IntP  q = 2^60 - c, c < 2^24 (q_0 and the special primes): values live lazily in [0, 16q), occasional three-instruction folds.
+//   IntP  q = 2^60 - c, c < 2^24 (q_0 and the special primes): values live lazily in [0, 16q), occasional three-instruction folds,
+//         Shoup quotients from the high halves only.
 //   FpA   the 45/46-bit scaling primes fit a double's 53-bit mantissa: residues are exact-integer doubles and a*w mod q is
 //         h = a*w; l = fma(a,w,-h); c = rint(a*(w/q)); r = fma(-c,q,h) + l — six FP64 instructions, no compares, no carries.
 // Between two passes FpA limbs travel as raw doubles in the (uint64) buffer; every limb leaves a transform as canonical uint64.
@@ -38,6 +39,7 @@ struct IntA {
     DEV void recentre(T &) const {}
     DEV void recentre_wide(T &) const {}
     DEV void mid(T &) const {}
+    DEV void fwd_fold(T &) const {}
     DEV T from_raw(u64 x) const { return x; }
     DEV u64 fin_fwd(T x) const {
         x = x >= q2 ? x - q2 : x;
@@ -48,37 +50,46 @@ struct IntA {
 
 // q = 2^60 - c with c < 2^24 (every 60-bit prime OpenFHE picks for this parameter set): values live lazily in [0, 16q) = [0, 2^64 - 16c)
 // and a conditional subtraction (five instructions per butterfly) becomes an occasional three-instruction fold x -> (x mod 2^60) +
-// (x >> 60) c, which lands any 64-bit x in [0, 2^60 + 15c] inside [0, 2q).  Forward (Cooley-Tukey): a Shoup product of ANY b < 2^64 is in
-// [0, 2q), a' = a + t and b' = a - t + 2q grow the bound by 2q per stage: q -> 15q over pass 1's seven stages, fold on reading pass 1's
-// output, 2q -> 8q -> 14q over phases A and B, fold, 6q after phase C, fold + one subtraction to the canonical residue.  Inverse
-// (Gentleman-Sande): sums double, d = a - b + 8q needs b < 8q, so at most three stages run between folds (the hooks the FP64 path
-// re-centres at, plus one inside pass 1's four-stage group).  Same residues as IntA after the final reduction.
+// (x >> 60) c, which lands any 64-bit x in [0, 2^60 + 15c] — "1+ q" below.
+// Round 4: the Shoup quotient is taken from the HIGH halves only, hi' = xh wh' + hi32(xl wh') + hi32(xh wl') in [hi - 2, hi]
+// (what is dropped — the low words of the two cross products and the whole of xl wl' — is below 3 2^64): two v_mul_hi_u32, one
+// v_mad_u64_u32 and one 64-bit add instead of four multiplies, three register moves and an add (the exact __umul64hi), 17 instead of
+// 21 instructions per butterfly.  The product is then in [0, 4q) instead of [0, 2q).
+// Forward (Cooley-Tukey): a' = a + t, b' = a - t + 4q grow the bound by 4q per stage, so THREE stages run between folds
+// (1+ -> 5 -> 9 -> 13 q; a fourth would pass 2^64): pass 1 folds after its third and sixth stage (fwd_fold) and leaves 5+ q, pass 2
+// folds on reading (from_raw), after phase A (fwd_fold), after phase B (mid) and in fin_fwd — three folds (nine instructions per
+// coefficient) more than the exact quotient needed, against 30 saved.  Inverse (Gentleman-Sande): sums double, d = a - b + 8q needs
+// b < 8q: from 1+ q the bounds run 4, 8, 16 q over three stages (products below 4q never lead), which is where the folds already
+// sat (the hooks the FP64 path re-centres at, plus one inside pass 1's four-stage group) — nothing added there.
+// Same residues as IntA after the final reduction.
 struct IntP {
     typedef u64 T;
     typedef ulonglong2 TW;
-    u64 q, q2, q8;
+    u64 q, q4, q8;
     unsigned c;
-    DEV IntP(const ModC &M) : q(M.q), q2(2 * M.q), q8(8 * M.q), c((unsigned)((1ull << 60) - M.q)) {}
+    DEV IntP(const ModC &M) : q(M.q), q4(4 * M.q), q8(8 * M.q), c((unsigned)((1ull << 60) - M.q)) {}
     DEV static TW tw(const ulonglong2 b) { return b; }
     DEV T from_canon(u64 x) const { return x; }
     DEV static T from_bits(u64 x) { return x; }
     DEV static u64 to_bits(T x) { return x; }
     DEV u64 fold(u64 x) const { return (x & ((1ull << 60) - 1)) + (u64)(unsigned)(x >> 60) * c; }
-    // Shoup product x w - floor(x w' / 2^64) q modulo 2^64, with -hi q = hi c - hi 2^60: one 32 x 32 multiply-add onto x w, and the high
-    // dword takes hi1 c - (hi0 << 28) — two multiplies instead of the three of a general 64 x 64 low product, and no borrow chain
+    // Shoup product x w - hi' q modulo 2^64 for ANY 64-bit x, in [0, 4q): -hi' q = hi' c - hi' 2^60, one 32 x 32 multiply-add onto
+    // x w, and the high dword takes hi1 c - (hi0 << 28) — two multiplies instead of the three of a general 64 x 64 low product, no
+    // borrow chain
     DEV u64 shoup(u64 x, const TW W) const {
-        const u64 hi = __umul64hi(x, W.y);
+        const unsigned xl = (unsigned)x, xh = (unsigned)(x >> 32), wl = (unsigned)W.y, wh = (unsigned)(W.y >> 32);
+        const u64 hi = (u64)xh * wh + ((u64)__umulhi(xl, wh) + (u64)__umulhi(xh, wl));
         const unsigned h0 = (unsigned)hi, h1 = (unsigned)(hi >> 32);
         const u64 t = x * W.x + (u64)h0 * c;
         return ((u64)((unsigned)(t >> 32) + h1 * c - (h0 << 28)) << 32) | (unsigned)t;  // the high dword alone: no 64-bit carry chain
     }
-    DEV void ct(T &a, T &b, const TW W) const {
+    DEV void ct(T &a, T &b, const TW W) const {  // [0, B) -> [0, B + 4q), B <= 12q
         const u64 t = shoup(b, W);
         const u64 u = a;
         a = u + t;
-        b = u - t + q2;
+        b = u - t + q4;
     }
-    DEV void gs(T &a, T &b, const TW W) const {
+    DEV void gs(T &a, T &b, const TW W) const {  // a, b < 8q -> a < 16q, b < 4q
         const u64 s = a + b;
         const u64 d = a - b + q8;
         b = shoup(d, W);
@@ -87,6 +98,7 @@ struct IntP {
     DEV void recentre(T &x) const { x = fold(x); }
     DEV void recentre_wide(T &x) const { x = fold(x); }
     DEV void mid(T &x) const { x = fold(x); }
+    DEV void fwd_fold(T &x) const { x = fold(x); }
     DEV T from_raw(u64 x) const { return fold(x); }
     DEV u64 fin_fwd(T x) const {
         x = fold(x);
@@ -142,6 +154,7 @@ struct FpA {
         if (!lean) recentre(x);
     }
     DEV void mid(T &) const {}
+    DEV void fwd_fold(T &) const {}
     DEV T from_raw(u64 x) const { return from_bits(x); }
     DEV u64 fin_fwd(T x) const {
         recentre(x);
