@@ -280,6 +280,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lane_stream.push_back(stream);
     if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("HYDIA_LANE0_SHARE")) lane0_share = std::max(0.05, std::min(0.95, atof(e)));
     for (int k = 1; k < nlanes; k++) {
         hipStream_t st;
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

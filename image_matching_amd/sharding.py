@@ -195,8 +195,11 @@ class DistDiagonalSender:
         mine = self._local_form()
         forms = [mine]
         if self.world > 1 and hasattr(self.cc, "db_kind"):
-            forms = [None] * self.world
-            self.dist.all_gather_object(forms, mine)
+            forms = []
+            for r in range(self.world):  # (broadcast_object_list is all the sender asks of `dist` elsewhere: stand-ins need no more)
+                box = [mine if r == self.rank else None]
+                self.dist.broadcast_object_list(box, src=r)
+                forms.append(box[0])
         self._form = mine
         held = sorted({f for f in forms if f is not None and f[0] != 0})
         if len(held) > 1:

@@ -121,7 +121,7 @@ def test_three_block_sender_bit_exact_full_ring(im, full, matvec):
 
 
 @pytest.mark.parametrize("blocks,matvec,babies,group,checks", [(4, None, 128, 8, "sim idx mem"), (13, None, 256, 2, "idx"),
-                                                               (16, "hoisted", 512, 8, "sim")])
+                                                               (10, "hoisted", 512, 2, "sim")])
 def test_auto_tiers_and_headline_kernel_bit_exact_full_ring(im, full, blocks, matvec, babies, group, checks):
     """Round-3 review: the auto rule's 128-baby (4-12 blocks: what BASELINE config 4's database and every 8-block shard of config 5
     get) and 256-baby (13-24 blocks) splits were compared with the oracle nowhere, and the headline loop-B kernel (k_hydia_tensor24 on
