@@ -549,10 +549,16 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     // transform itself and leaves its raw image in yu (HYDIA_RELIN_SEPARATE_INTT: through acc, as before)
     const bool tail_in_ip = !relin_separate_intt;
     const bool fused_tail = fip && tail_in_ip && prm.logN == 15;
+    const LimbSel qsel_full = sel_q(nl);
+    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
+    const ScaleSel pinv_sel = scale_of(qsel_full, pinv, false);
+    // (round 4) the dropped limb's sums take the same tail inside the merged kernel: (sum P^{-1} + d_l)(x2), inverse pass 2, row 0 of yu
+    const DropLimb drop{l, dbl ? 1 : 0, pinv_sel.s[l], pinv_sel.s_sh[l], c.d, c.ct_elems(), c.poly_elems()};
+    bool drop_done = false;
     timer_begin("ks_inner_product");
     if (fip)
-        hk::ntt15_p2_inner_product(stream, tabs, d_mod, dig, (size_t)nd * nE * N, nd, X, nl, nP, nT, alpha, relin_key.d_cell, relin_key.d, c2,
-                                   c.ct_elems(), acc, fused_tail ? yu : nullptr, yu_outer, 1);
+        drop_done = hk::ntt15_p2_inner_product(stream, tabs, d_mod, dig, (size_t)nd * nE * N, nd, X, nl, nP, nT, alpha, relin_key.d_cell, relin_key.d,
+                                               c2, c.ct_elems(), acc, fused_tail ? yu : nullptr, yu_outer, 1, fused_tail ? &drop : nullptr);
     else
         hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
     timer_end("ks_inner_product");
@@ -560,9 +566,6 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     // limb l of the would-be ModDown output (+ d_l, doubled) replaces row l of the accumulator (nothing else reads that row), so that
     // ONE inverse transform takes rows l .. nE-1 — the dropped limb and the special-prime limbs (pre-multiplied by (P/p_k)^{-1}) —
     // to the coefficient domain: yu [XP][1 + nP][N], row 0 = u
-    const LimbSel qsel_full = sel_q(nl);
-    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
-    const ScaleSel pinv_sel = scale_of(qsel_full, pinv, false);
     if (!fused_tail)
         hk::moddown_last_limb(stream, d_mod, N, acc, nE, c.d, c.ct_elems(), c.poly_elems(), acc + (size_t)l * N, (size_t)nE * N, XP, l,
                               pinv_sel.s[l], pinv_sel.s_sh[l], dbl ? 1 : 0);
@@ -577,8 +580,9 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     const bool cfu = cf_ok() && (q[l] >> 50) == 0;  // the fused kernel carries the dropped limb's centred residue as a double
     const bool cf_pre = cfu && hk::ntt15_colfuse_small(XP, 1);  // few workgroups: pass 1' as its own (wider) launch
     if (fused_tail) {
-        hk::ntt15_inverse_p2_last_limb(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
-                                       c.d, c.ct_elems(), c.poly_elems(), dbl ? 1 : 0);
+        if (!drop_done)
+            hk::ntt15_inverse_p2_last_limb(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
+                                           c.d, c.ct_elems(), c.poly_elems(), dbl ? 1 : 0);
         if (!cfu || cf_pre) hk::ntt15_inverse_p1(stream, tabs, yu, yu_outer, XP, tail, scale_of(tail, tail_scale, true));
     } else if (cfu && !cf_pre) {
         hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, tail);

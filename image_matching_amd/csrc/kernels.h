@@ -27,6 +27,7 @@ struct NttTables {
     int one_pass_min;              // HYDIA_NTT_1PASS_MIN: smallest launch (limb-polynomials) that takes the one-pass kernel (default 1024)
     int two_ip_launches;           // HYDIA_RELIN_TWO_IP_LAUNCHES: Q and special-prime halves of the fused inner product as two launches
     int ip_group;                  // HYDIA_IP_GROUP: ciphertexts per interleaving group of the merged inner-product kernel (default 8)
+    int no_drop_in_ip;             // HYDIA_NO_DROP_IN_IP: the dropped limb's inverse pass 2 as its own launch (round 3's form)
     int generic;                   // HYDIA_NTT_GENERIC: the ring-size-generic transform kernels also at N = 2^15 (parity variant)
 };
 
@@ -85,6 +86,19 @@ struct IpArgs {
     u64 *inv_out;
     size_t inv_outer;  // elements per polynomial of inv_out
     int inv_row0;
+    // merged ModDown + Rescale (round 4): the Q limb drop_l (the limb the rescale drops; -1 = none) takes the tail as well — its two
+    // sums become the dropped limb of the would-be ModDown output, (sum drop_mul + drop_add[x, p, drop_l])(x2), and go through the first
+    // pass of the inverse transform into row inv_row0 - 1; nothing of that limb reaches acc (nobody reads it)
+    int drop_l, drop_dbl;
+    u64 drop_mul, drop_mul_sh;
+    const u64 *drop_add;  // [x][p][..][N]: + drop_add[x*drop_add_x + p*drop_add_p + drop_l*N + c]
+    size_t drop_add_x, drop_add_p;
+};
+struct DropLimb {  // host side of the same (ntt15_p2_inner_product)
+    int l, dbl;
+    u64 mul, mul_sh;
+    const u64 *add;
+    size_t add_x, add_p;
 };
 // store mode 5 = mode 1 whose `in` operand (the key-switching accumulator of the Q limbs) is never materialised: the epilogue forms
 // sum_d dig[d][j][c] * key_x[d][p][j][c] itself from the shared digits (L2-resident) and rotation x's key (loop A)
@@ -294,9 +308,10 @@ void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *a
 // second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every
 // extended limb [x][nd][nE][N]; acc[x][2][nE][N] = sum_d NTT(dig[x][d][t]) * key[d][.][t]  (+ own-digit limbs from c2).
 // inv_out != nullptr: the special-prime rows skip acc (see IpArgs)
-void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,
+// returns true when the launch also produced the dropped limb's inverse-pass-2 image (`drop` given and the merged kernel ran)
+bool ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,
                             int nl, int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
-                            u64 *inv_out = nullptr, size_t inv_outer = 0, int inv_row0 = 0);
+                            u64 *inv_out = nullptr, size_t inv_outer = 0, int inv_row0 = 0, const DropLimb *drop = nullptr);
 void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel);
 // second pass alone, in place on pass-1 output (plain store)
 void ntt15_forward_p2(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel);

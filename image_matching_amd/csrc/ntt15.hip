@@ -673,8 +673,19 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
                     for (int pp = 0; pp < 2; pp++) {
                         IpAcc<A> *ip = pp == 0 ? ipb : ipa;
-                        T c0 = ar.from_canon(ip[0].fin(ar, M, NP + 1)), c1 = ar.from_canon(ip[1].fin(ar, M, NP + 1)),
-                          c2 = ar.from_canon(ip[2].fin(ar, M, NP + 1)), c3 = ar.from_canon(ip[3].fin(ar, M, NP + 1));
+                        u64 f4[4] = {ip[0].fin(ar, M, NP + 1), ip[1].fin(ar, M, NP + 1), ip[2].fin(ar, M, NP + 1), ip[3].fin(ar, M, NP + 1)};
+                        if (ip_t == stp.ip.drop_l) {  // workgroup-uniform: the limb the rescale drops — (sum P^{-1} + d_l)(x2), k_moddown_last_limb's arithmetic
+                            const u64 *pa = stp.ip.drop_add + (size_t)xp0 * stp.ip.drop_add_x + (size_t)pp * stp.ip.drop_add_p + (size_t)ip_t * 32768 + ci;
+                            const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(pa), d1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
+                            const u64 dv[4] = {d0.x, d0.y, d1.x, d1.y};
+                            const u64 qq = M.q;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                f4[k] = addmod(mulmod_shoup(f4[k], stp.ip.drop_mul, stp.ip.drop_mul_sh, qq), dv[k], qq);
+                                if (stp.ip.drop_dbl) f4[k] = addmod(f4[k], f4[k], qq);
+                            }
+                        }
+                        T c0 = ar.from_canon(f4[0]), c1 = ar.from_canon(f4[1]), c2 = ar.from_canon(f4[2]), c3 = ar.from_canon(f4[3]);
                         ar.gs(c0, c1, I14a);
                         ar.gs(c2, c3, I14b);
                         ar.gs(c0, c2, I13);
@@ -826,6 +837,7 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip_all(NttTables T, const u64 
     const int si = r / xb, x = grp * xb + (r - si * xb);
     const int pc = si * nP / nS, pc1 = (si + 1) * nP / nS;
     if (pc1 > pc) p2_ip_workgroup<ND, false, true, SWZ>(T, dig, dxs, nl + pc, x, stp, blockIdx.x, lds);
+    else if (si - pc == stp.ip.drop_l) p2_ip_workgroup<ND - 1, true, true, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);  // (ND >= 2 images: enough for the tail)
     else p2_ip_workgroup<ND - 1, true, false, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);
 }
 
@@ -1113,9 +1125,9 @@ __global__ __launch_bounds__(1024) void k_ntt15_1p(NttTables T, const ulonglong2
 
 namespace hk {
 
-void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dxs, int nd, int X, int nl,
+bool ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dxs, int nd, int X, int nl,
                             int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
-                            u64 *inv_out, size_t inv_outer, int inv_row0) {
+                            u64 *inv_out, size_t inv_outer, int inv_row0, const DropLimb *drop) {
     const int nE = nl + nP;
     NttStore stp{};
     stp.mode = 4;
@@ -1131,12 +1143,22 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
     stp.ip.inv_out = inv_out;
     stp.ip.inv_outer = inv_outer;
     stp.ip.inv_row0 = inv_row0;
+    stp.ip.drop_l = -1;
     // Q limbs: NP = nd - 1 pass-1 digits in (+ the limb's own residues), two accumulator rows out; special-prime limbs: nd digits in, two
     // rows out; the key tiles are shared by all x (L2)
     const double bytes_q = nd >= 2 ? ((nd - 1) + 1 + 2.0) * nl * X * 262144.0 : 0.0, bytes_p = (nd + 2.0) * nP * X * 262144.0;
     const bool merged = inv_out && nd >= 2 && nd <= 4 && !T.two_ip_launches;
     char name[64];
     if (merged) {
+        if (drop && !T.no_drop_in_ip && inv_row0 >= 1 && drop->l == nl - 1) {  // the dropped limb rides the tail (one launch and a round trip of that row less)
+            stp.ip.drop_l = drop->l;
+            stp.ip.drop_dbl = drop->dbl;
+            stp.ip.drop_mul = drop->mul;
+            stp.ip.drop_mul_sh = drop->mul_sh;
+            stp.ip.drop_add = drop->add;
+            stp.ip.drop_add_x = drop->add_x;
+            stp.ip.drop_add_p = drop->add_p;
+        }
         snprintf(name, sizeof name, "k_ntt15_p2_ip_all<%d>", nd);
         ledger_add(name, bytes_q + bytes_p);
         int xb = T.ip_group;  // ciphertexts per interleaving group (HYDIA_IP_GROUP; must divide X)
@@ -1144,7 +1166,7 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
         if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip_all<2>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
         else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip_all<3>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
         else hipLaunchKernelGGL((k_ntt15_p2_ip_all<4>), dim3(16, (nl + nP) * X), dim3(256), 0, st, T, dig, dxs, X, xb, stp);
-        return;
+        return stp.ip.drop_l >= 0;
     }
     if (nd >= 2) {
         snprintf(name, sizeof name, "k_ntt15_p2_ip<%d, true, false>", nd - 1 > 3 ? 3 : nd - 1);
@@ -1171,12 +1193,13 @@ void ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
         else if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip<2, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
         else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip<3, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
         else hipLaunchKernelGGL((k_ntt15_p2_ip<4, false, true>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
-        return;
+        return false;
     }
     if (nd == 1) hipLaunchKernelGGL((k_ntt15_p2_ip<1, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
     else if (nd == 2) hipLaunchKernelGGL((k_ntt15_p2_ip<2, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
     else if (nd == 3) hipLaunchKernelGGL((k_ntt15_p2_ip<3, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
     else hipLaunchKernelGGL((k_ntt15_p2_ip<4, false>), dim3(16, nP * X), dim3(256), 0, st, T, dig, dxs, X, nl, stp);
+    return false;
 }
 
 // ---- launch plumbing.  With the one-pass kernel enabled (HYDIA_NTT_1PASS) a LimbSel is cut into maximal runs of slots whose moduli
