@@ -357,6 +357,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
         tabs.one_pass_min = mn ? atoi(mn) : 1024;
         tabs.two_ip_launches = getenv("HYDIA_RELIN_TWO_IP_LAUNCHES") ? 1 : 0;
         tabs.no_drop_in_ip = getenv("HYDIA_NO_DROP_IN_IP") ? 1 : 0;
+        tabs.int_epilogue = getenv("HYDIA_INT_EPILOGUE") ? 1 : 0;
         const char *g = getenv("HYDIA_IP_GROUP");
         tabs.ip_group = g && atoi(g) > 0 ? atoi(g) : 8;
         tabs.generic = getenv("HYDIA_NTT_GENERIC") ? 1 : 0;

@@ -27,6 +27,7 @@ struct NttTables {
     int one_pass_min;              // HYDIA_NTT_1PASS_MIN: smallest launch (limb-polynomials) that takes the one-pass kernel (default 1024)
     int two_ip_launches;           // HYDIA_RELIN_TWO_IP_LAUNCHES: Q and special-prime halves of the fused inner product as two launches
     int ip_group;                  // HYDIA_IP_GROUP: ciphertexts per interleaving group of the merged inner-product kernel (default 8)
+    int int_epilogue;              // HYDIA_INT_EPILOGUE: merged ModDown + Rescale epilogue in integers for every limb (round 3's form)
     int no_drop_in_ip;             // HYDIA_NO_DROP_IN_IP: the dropped limb's inverse pass 2 as its own launch (round 3's form)
     int generic;                   // HYDIA_NTT_GENERIC: the ring-size-generic transform kernels also at N = 2^15 (parity variant)
 };
@@ -131,6 +132,7 @@ struct NttStore {
     int has_addc;         // mode 2: + addc[j] on polynomials with xp % npoly == 0
     int npoly;
     u64 addc[HY_LC_LIMBS];
+    int int_epilogue;     // mode 3: integer (Shoup) epilogue for every limb (HYDIA_INT_EPILOGUE; default: FP64 for the limbs below 2^47)
     IpArgs ip;            // mode 4
     LoopAIp la;           // mode 5
 };

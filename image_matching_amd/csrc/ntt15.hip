@@ -453,6 +453,53 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     }
 }
 
+// Merged ModDown + Rescale epilogue (mode 3) of a limb below 2^47 on the FP64 pipe (round 4).  The integer form runs two Shoup products
+// with their conditional subtractions per coefficient on the canonical transform output (57 instructions with fin_fwd); but
+//   ((in P^{-1} + ex)(x2) - v) q_l^{-1} (+- sb)(+ addc)  =  in K1 + ex K2 - v K3 (+- sb)(+ addc),
+// K1 = P^{-1} (x2) q_l^{-1}, K2 = (x2) q_l^{-1}, K3 = q_l^{-1} mod q, so three exact FP64 products with precomputed quotients take the
+// operands as they are — `in`, `ex`, `sb` canonical, v the transform's UNREDUCED output (|v| < 2^50) — and ONE reduction finishes:
+// |sum| < 6q, exact in a double.  35 instructions; the same canonical residue (every step is exact modulo q).
+struct Epi3Fp {
+    double2 k1, k2, k3;
+    double addc;
+    template <int ST, class A>
+    DEV static Epi3Fp make(const NttStore &st, const A &, const ModC &, int) {
+        return Epi3Fp{};
+    }
+};
+template <>
+DEV Epi3Fp Epi3Fp::make<3, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) {
+    Epi3Fp e;
+    const u64 m2 = st.mul2.s[j];
+    const u64 two = st.dbl ? addmod(m2, m2, M.q) : m2;  // (x2) q_l^{-1}
+    e.k1 = ar.tw8(FpA::u2d(mulmod(st.mul.s[j], two, M)));
+    e.k2 = ar.tw8(FpA::u2d(two));
+    e.k3 = ar.tw8(FpA::u2d(m2));
+    e.addc = st.has_addc ? FpA::u2d(st.addc[j]) : 0.0;
+    return e;
+}
+DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigned idx, const double (&v)[4], const P2Pre &pre, const Epi3Fp &e) {
+    constexpr size_t N = 32768;
+    const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
+    const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
+    const u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
+    const bool addc = st.has_addc && (xp % st.npoly) == 0;
+    u64 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double t = ar.mulmod(FpA::u2d(iv[k]), e.k1) - ar.mulmod(v[k], e.k3);
+        if (pre.has_ex) t += ar.mulmod(FpA::u2d(ev[k]), e.k2);
+        if (pre.has_sb) t += st.sub_add ? FpA::u2d(sv[k]) : -FpA::u2d(sv[k]);
+        if (addc) t += e.addc;
+        r[k] = ar.fin_fwd(t);
+    }
+    u64 *o3 = st.out + ((size_t)xp * st.nl + j) * N;
+    *reinterpret_cast<ulonglong2 *>(o3 + idx) = make_ulonglong2(r[0], r[1]);
+    *reinterpret_cast<ulonglong2 *>(o3 + idx + 2) = make_ulonglong2(r[2], r[3]);
+}
+template <class A>
+DEV void p2_finish3_fp(const NttStore &, const A &, int, int, unsigned, const typename A::T (&)[4], const P2Pre &, const Epi3Fp &) {}
+
 // The LDS image of a pass-2 workgroup: 8 blocks x 8 rows x 32 coefficients per polynomial.  Padded (rows of 36: phase B's (row, 4k + b)
 // accesses of a half-wave hit 32 distinct bank pairs) or, SWZ, unpadded with the position XOR-ed by 4 x row — the same property at
 // 16 KiB instead of 18 per polynomial, which lets the three-digit fused inner product keep THREE workgroups on a CU (3 x 48 KiB) where
@@ -604,6 +651,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         // the merged epilogues' operands are fetched one half at a time (the second half's while the first half is finished): 109 / 120
         // instead of 136 / 150 registers, i.e. 4 instead of 3 waves per SIMD (-0.4 ms per query at 2^14, -0.8 ms at 2^20)
         constexpr bool SPLIT = ST == 5 || ST == 3;
+        const Epi3Fp epi = Epi3Fp::make<ST, A>(stp, ar, M, slot);
         P2Pre pre[2][NP];
         if (ST != 0 && ST != 4 && ST != 6) {
 #pragma unroll
@@ -650,6 +698,9 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     o1.x = ar.fin_fwd(c2); o1.y = ar.fin_fwd(c3);
                     *reinterpret_cast<ulonglong2 *>(d[p] + e) = o0;
                     *reinterpret_cast<ulonglong2 *>(d[p] + e + 2) = o1;
+                } else if (ST == 3 && std::is_same<A, FpA>::value && !stp.int_epilogue) {
+                    const T cv[4] = {c0, c1, c2, c3};
+                    p2_finish3_fp(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi);
                 } else {
                     const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
                     p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[SPLIT ? 0 : hh][p]);
@@ -1275,10 +1326,12 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
             per = 2.5 * 262144.0 + stp.la.nd * 32768.0 * (stp.la.packed_nQ > 0 ? (6.0 * (nsl - 1) + 8.0) / nsl : 8.0);
         ledger_add(name, per * X * nsl);
     }
+    NttStore sv = stp;
+    sv.int_epilogue = T.int_epilogue;
     if (pair_polys(X, nsl))
-        hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
+        hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
     else
-        hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, stp);
+        hipLaunchKernelGGL((k_ntt15_p2<false, 1, ST>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
 }
 template <int LD, int ST>
 static void forward_runs(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel,
