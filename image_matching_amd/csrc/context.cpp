@@ -280,6 +280,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lane_stream.push_back(stream);
     if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
+    if (getenv("HYDIA_NO_PROD_FUSE")) prod_fuse = false;
     if (const char *e = getenv("HYDIA_LANE0_SHARE")) lane0_share = std::max(0.05, std::min(0.95, atof(e)));
     for (int k = 1; k < nlanes; k++) {
         hipStream_t st;
@@ -347,6 +348,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     tabs = NttTables{d_tw, d_tw_sh, d_itw, d_itw_sh, d_mod, (const ulonglong2 *)d_twp, (const ulonglong2 *)d_itwp,
                      (const ulonglong2 *)d_twf, (const ulonglong2 *)d_itwf, (const double *)d_twd, (const double *)d_itwd, 0u};
     if (getenv("HYDIA_NTT_INT")) tabs.twf = tabs.itwf = nullptr;  // A/B switch: integer butterflies for every limb
+    getenv_int_arith = getenv("HYDIA_NTT_INT") != nullptr;
     tabs.fp_mask = 0;
     for (int m = 0; m < nT; m++)
         if (tabs.twf != nullptr && mod[m].ks + 2 <= 47) tabs.fp_mask |= 1u << m;

@@ -188,7 +188,8 @@ const Context::CfPlan &Context::cf_plan_moddown_rescale(int nl, bool dbl) {
 // launch serve all digits; the forward transforms run per digit (the digit's own limbs are skipped) unless the launch is small
 // (a query's fixed-cost tail), where one launch over every row of every digit beats nd launches that each leave most CUs idle —
 // the own rows then hold transformed garbage nobody reads (copy_own overwrites them, the inner product reads the input itself).
-void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own, bool p1_only) {
+void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own, bool p1_only, const ProdSrc *ps, u64 *d2_out) {
+    if (ps && !cf_ok()) throw std::runtime_error("hydia: fused product outside the column-fused pipeline");
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha;
     const size_t dig_x = (size_t)nd * nE * N;
     const LimbSel esel = sel_ext(nl), qsel = sel_q(nl);
@@ -198,8 +199,14 @@ void Context::modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig
         // inverse pass 2' of every limb, then ONE column-fused launch: pass 1' of a digit's limbs, conversion, pass 1 of its targets
         const CfPlan &cp = cf_plan_modup(nl);
         const bool small = hk::ntt15_colfuse_small(X, nd);  // few workgroups: the inverse transform as its own (wider) launch
-        if (small) ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
-        else hk::ntt15_inverse_p2(stream, tabs, c, y, c_outer, (size_t)nl * N, X, qsel);
+        if (ps) {  // d2 = a1 b1 in the load of inverse pass 2' (+ kept in d2_out); small launches: pass 1' as its own launch
+            hk::ntt15_inverse_p2_prod(stream, tabs, *ps, y, (size_t)nl * N, X, qsel, d2_out);
+            if (small) hk::ntt15_inverse_p1(stream, tabs, y, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
+        } else if (small) {
+            ntt_inv(c, y, c_outer, (size_t)nl * N, X, qsel, scale_of(qsel, pl.inv, true));
+        } else {
+            hk::ntt15_inverse_p2(stream, tabs, c, y, c_outer, (size_t)nl * N, X, qsel);
+        }
         hk::ntt15_colfuse(stream, tabs, y, (size_t)nl * N, dig, dig_x, X, cp.dev, cp.host.data(), nd, small);
         pool.put(y);
         if (!p1_only) {
@@ -530,16 +537,19 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     c = std::move(out);
 }
 // the merged pipeline: c [X][3][nl][N] -> out_d [X][2][nl - 1][N]
-void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d) {
+void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps) {
     const int nl = c.nl, l = nl - 1;
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     // relinearise (ModUp nd nE, ModDown 2 (nP + nl)) + rescale (2 nl) transforms per ciphertext: 80 + 24 at nl = 12
     op_bytes("op:relin_rescale", N, (double)X * (nd * nE + 2 * nP + 4 * nl), (double)nd * 2 * nE * N * 8);
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
-    const u64 *c2 = c.d + 2 * c.poly_elems();
+    // fused product: d2 is formed in the inverse transform's load and kept (compact) for the inner product's own-digit rows
+    u64 *d2buf = ps ? pool.get((size_t)X * nl * N * sizeof(u64)) : nullptr;
+    const u64 *c2 = ps ? d2buf : c.d + 2 * c.poly_elems();
+    const size_t c2_xs = ps ? (size_t)nl * N : c.ct_elems();
     // the inner product reads a digit's own limbs from c2, and (fuse_ip) consumes the ModUp transforms' second pass directly
     const bool fip = fuse_ip;
-    modup_digits(c2, c.ct_elems(), X, nl, dig, /*copy_own=*/false, /*p1_only=*/fip);
+    modup_digits(c2, c2_xs, X, nl, dig, /*copy_own=*/false, /*p1_only=*/fip, ps, d2buf);
     const LimbSel esel = sel_ext(nl);
     u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
     // yu [XP][1 + nP][N]: row 0 = the dropped limb u, rows 1.. = the special-prime limbs, on their way to the coefficient domain
@@ -553,16 +563,18 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
     const ScaleSel pinv_sel = scale_of(qsel_full, pinv, false);
     // (round 4) the dropped limb's sums take the same tail inside the merged kernel: (sum P^{-1} + d_l)(x2), inverse pass 2, row 0 of yu
-    const DropLimb drop{l, dbl ? 1 : 0, pinv_sel.s[l], pinv_sel.s_sh[l], c.d, c.ct_elems(), c.poly_elems()};
+    const DropLimb drop{l, dbl ? 1 : 0, pinv_sel.s[l], pinv_sel.s_sh[l], c.d, ps ? 0 : c.ct_elems(), ps ? 0 : c.poly_elems(), ps};
     bool drop_done = false;
     timer_begin("ks_inner_product");
     if (fip)
         drop_done = hk::ntt15_p2_inner_product(stream, tabs, d_mod, dig, (size_t)nd * nE * N, nd, X, nl, nP, nT, alpha, relin_key.d_cell, relin_key.d,
-                                               c2, c.ct_elems(), acc, fused_tail ? yu : nullptr, yu_outer, 1, fused_tail ? &drop : nullptr);
+                                               c2, c2_xs, acc, fused_tail ? yu : nullptr, yu_outer, 1, fused_tail ? &drop : nullptr);
     else
-        hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c.ct_elems(), alpha, nl);
+        hk::inner_product(stream, d_mod, N, dig, (size_t)nd * nE * N, nd, relin_key.d_cell, 1, nT, acc, X, esel, c2, c2_xs, alpha, nl);
     timer_end("ks_inner_product");
     pool.put(dig);
+    if (d2buf) pool.put(d2buf);
+    if (ps && !(drop_done && fused_tail)) throw std::runtime_error("hydia: fused product outside the merged pipeline (prod_fusable out of step)");
     // limb l of the would-be ModDown output (+ d_l, doubled) replaces row l of the accumulator (nothing else reads that row), so that
     // ONE inverse transform takes rows l .. nE-1 — the dropped limb and the special-prime limbs (pre-multiplied by (P/p_k)^{-1}) —
     // to the coefficient domain: yu [XP][1 + nP][N], row 0 = u
@@ -619,9 +631,13 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     stp.mul = pinv_sel;
     stp.mul2 = scale_of(qsel, qi, false);
     stp.addend = c.d;
-    stp.add_x = c.ct_elems();
-    stp.add_p = c.poly_elems();
+    stp.add_x = ps ? 0 : c.ct_elems();
+    stp.add_p = ps ? 0 : c.poly_elems();
     stp.add_polys = 2;
+    if (ps) {  // d0, d1 of the product are formed in the epilogue
+        stp.has_prod = 1;
+        stp.prod = *ps;
+    }
     stp.dbl = dbl ? 1 : 0;
     stp.sub = sub ? sub->d : nullptr;
     stp.sub_ls = sub ? sub->lstride : 0;
@@ -707,6 +723,7 @@ Ct Context::lincomb_multi(const std::vector<const Ct *> &terms, const std::vecto
     LinCombMulti lc{};
     lc.nterms = nt;
     lc.K = K;
+    lc.fp = (tabs.twf != nullptr || prm.logN != 15) && !getenv_int_arith ? 1 : 0;
     if (lcm_stage.size() >= 64) {  // uploads are asynchronous: recycle the staging buffers only behind a stream fence
         sync_all();
         lcm_stage.clear();
@@ -758,12 +775,37 @@ Ct Context::mult_norelin_sub(const Ct &a, const Ct &b, const Ct &c) {
     hk::tensor(stream, d_mod, N, a.d, b.d, o.d, a.X, a.nl, a.lstride, b.lstride, c.d, c.lstride, &kap);
     return o;
 }
+// the conditions under which relin_rescale_into runs its merged pipeline end to end (every consumer of d0, d1, d2 can form them)
+bool Context::prod_fusable(int nl) const {
+    const int l = nl - 1, nd = (nl + alpha - 1) / alpha;
+    return prod_fuse && prm.logN == 15 && merge_rescale && fuse_ip && !relin_separate_intt && cf_ok() && l >= 1 && l <= HY_LC_LIMBS && nd >= 2 &&
+           nd <= 4 && !tabs.two_ip_launches && !tabs.no_drop_in_ip && (q[l] >> 50) == 0 && relin_key.d != nullptr;
+}
+Ct Context::mult_relin_rescale(const Ct &a, const Ct &b, bool dbl, const Ct *sub, const double *addc, bool sub_is_add) {
+    if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
+    const int nl = a.nl, l = nl - 1;
+    if (!prod_fusable(nl) || (sub && (sub->X != a.X || sub->npoly != 2 || sub->nl < l))) {
+        Ct o = mult_norelin(a, b);
+        relin_rescale(o, dbl, sub, addc, sub_is_add);
+        return o;
+    }
+    op_bytes("op:mult_norelin", N, 0, 7.0 * a.X * a.nl * N * 8);  // the inherent bytes of the product stay what they were
+    Ct shape;  // shape and scale of the degree-2 ciphertext that is never formed
+    shape.ctx = this;
+    shape.X = a.X;
+    shape.npoly = 3;
+    shape.nl = shape.lstride = nl;
+    shape.scale = a.scale * b.scale;
+    shape.view = true;
+    const ProdSrc ps{a.d, b.d, a.ct_elems(), a.poly_elems(), b.ct_elems(), b.poly_elems()};
+    Ct out(this, a.X, 2, l, shape.scale / (double)q[l]);
+    relin_rescale_into(shape, dbl, sub, addc, sub_is_add, out.d, &ps);
+    return out;
+}
 Ct Context::mult(const Ct &a, const Ct &b) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
-    Ct o = mult_norelin(x, y);
-    relin_rescale(o);
-    return o;
+    return mult_relin_rescale(x, y);
 }
 // EvalRotate on every ciphertext of the batch (EvalSum's step, sender_diag.cpp:47)
 Ct Context::rotate(const Ct &a, int rot) {
@@ -932,23 +974,19 @@ Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
         cx->relin_rescale(o, true, nullptr, nullptr);
         return o;
     }
-    Ct o = cx->mult_norelin(x, y);
-    cx->relin_rescale(o, true, nullptr, &minus_one);
-    return o;
+    return cx->mult_relin_rescale(x, y, true, nullptr, &minus_one);
 }
 // a*b (relinearised, rescaled) + r with r already at the product's scale; r joins in the rescale epilogue when it has the limbs
 Ct mult_add(Context *cx, const Ct &a, const Ct &b, Ct &r) {
     const int nl = std::min(a.nl, b.nl);
     Ct x = a.alias(nl), y = b.alias(nl);
-    Ct o = cx->mult_norelin(x, y);
     if (r.nl >= nl - 1) {
         Ct rv = r.alias(nl - 1);
-        cx->relin_rescale(o, false, &rv, nullptr, true);
-    } else {
-        cx->relin_rescale(o);
-        cx->drop_to(o, r.nl);
-        cx->add_inplace(o, r);
+        return cx->mult_relin_rescale(x, y, false, &rv, nullptr, true);
     }
+    Ct o = cx->mult_relin_rescale(x, y);
+    cx->drop_to(o, r.nl);
+    cx->add_inplace(o, r);
     return o;
 }
 int leaf_nl(Cheb &ch, const double *c, int deg) {

@@ -253,9 +253,13 @@ struct Context : HostParams {
     void ntt_fwd(u64 *base, size_t outer, int X, const LimbSel &s);
     void ntt_inv(const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &s, const ScaleSel &sc);
     // ModUp: c [X][nl][N] at stride c_outer -> dig [X][nd][nE][N]
-    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true, bool p1_only = false);
+    // ps != nullptr (column-fused path only): the polynomial is d2 = a1 b1 of a fused product, formed in the load of the inverse
+    // transform and also written to d2_out, compact [X][nl][N]
+    void modup_digits(const u64 *c, size_t c_outer, int X, int nl, u64 *dig, bool copy_own = true, bool p1_only = false,
+                      const ProdSrc *ps = nullptr, u64 *d2_out = nullptr);
     bool fuse_loop_a = true;    // loop A: Q-limb inner product inside the ModDown transform's epilogue (HYDIA_NO_FUSE_LOOPA)
     bool fork_products = true;  // comparator: independent products of a one-block query on two lanes (HYDIA_NO_FORK)
+    bool getenv_int_arith = false;  // HYDIA_NTT_INT: integer arithmetic everywhere (also the coefficient-wise kernels' FP64 paths)
     bool fuse_ip = true;  // relinearisation: second NTT pass of ModUp fused with the inner product (HYDIA_NO_FUSE_IP)
     // inner product with X keys + ModDown (+ addend, + automorphism): out [X][2][nl][N]
     // keys_packed_nQ > 0: d_keys point at packed keys (hk::key_pack)
@@ -270,7 +274,13 @@ struct Context : HostParams {
     // the dropped limb of the ModDown output is obtained in the coefficient domain, so ModDown's and Rescale's
     // corrections share a single forward NTT per remaining limb ((l+1) transforms per polynomial saved)
     void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
-    void relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d);
+    // ps != nullptr: c carries shape and scale only (X, nl, scale; no data) — the degree-2 ciphertext is the product ps and is never formed
+    void relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps = nullptr);
+    // (a b) relinearised (doubled) and rescaled (+- sub)(+ addc): EvalMultNoRelin + relin_rescale, with the tensor fused into its
+    // consumers where the merged pipeline runs (prod_fusable)
+    bool prod_fuse = true;  // HYDIA_NO_PROD_FUSE: k_tensor materialises every degree-2 ciphertext (round 3's form)
+    bool prod_fusable(int nl) const;
+    Ct mult_relin_rescale(const Ct &a, const Ct &b, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
     bool merge_rescale = true;      // HYDIA_NO_MERGE_RESCALE: run the two steps separately (A/B)
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged

@@ -59,6 +59,7 @@ struct LinComb {
 // once, K outputs are written.  tab (device): K blocks of [HY_LC_TERMS][HY_LC_LIMBS] constants followed by [HY_LC_LIMBS] c0.
 struct LinCombMulti {
     int nterms, K;
+    int fp;               // limbs below 2^47 on the FP64 pipe (HYDIA_NTT_INT turns it off: 128-bit integer sums everywhere)
     const u64 *src[HY_LC_TERMS];
     int ls[HY_LC_TERMS];
     const u64 *tab;
@@ -75,6 +76,14 @@ struct NttLoad {
 // Fused epilogue of its second pass: what is done with the evaluation-form value v of limb j
 // store mode 4: the forward transform's results are consumed by the key-switching inner product instead of being stored —
 // a workgroup transforms limb t of EVERY digit that has to be extended to it, multiplies by the key and writes acc only
+// A ct x ct product whose tensor is formed where it is consumed (round 4) instead of by k_tensor: d0 = a0 b0, d1 = a0 b1 + a1 b0 go into
+// the merged ModDown + Rescale epilogue (and the dropped limb's tail), d2 = a1 b1 into the load of the relinearisation's inverse
+// transform — the degree-2 ciphertext [x][3][nl][N] never exists in HBM (7 limb-polynomials of traffic per limb and ciphertext and
+// one launch less per product).  a, b: [x][2][..][N] views, limb j of polynomial p of ciphertext x at a + x a_x + p a_p + j N.
+struct ProdSrc {
+    const u64 *a, *b;
+    size_t a_x, a_p, b_x, b_p;
+};
 struct IpArgs {
     const u64 *key;   // [nd][2][nT][N]
     int nT, nE, nl, alpha;
@@ -94,12 +103,15 @@ struct IpArgs {
     u64 drop_mul, drop_mul_sh;
     const u64 *drop_add;  // [x][p][..][N]: + drop_add[x*drop_add_x + p*drop_add_p + drop_l*N + c]
     size_t drop_add_x, drop_add_p;
+    int drop_has_prod;    // the addend is the product's d_p at that limb, formed from drop_prod (drop_add unused)
+    ProdSrc drop_prod;
 };
 struct DropLimb {  // host side of the same (ntt15_p2_inner_product)
     int l, dbl;
     u64 mul, mul_sh;
     const u64 *add;
     size_t add_x, add_p;
+    const ProdSrc *prod;  // non-null: the addend is a product's d_p (add unused)
 };
 // store mode 5 = mode 1 whose `in` operand (the key-switching accumulator of the Q limbs) is never materialised: the epilogue forms
 // sum_d dig[d][j][c] * key_x[d][p][j][c] itself from the shared digits (L2-resident) and rotation x's key (loop A)
@@ -132,6 +144,8 @@ struct NttStore {
     int has_addc;         // mode 2: + addc[j] on polynomials with xp % npoly == 0
     int npoly;
     u64 addc[HY_LC_LIMBS];
+    int has_prod;         // mode 3: the addend is d_p of the product `prod` (addend unused); inverse load mode 8: the input is d2 = a1 b1 of `prod`
+    ProdSrc prod;         //         (mode 8 also writes d2 to `out`, compact [x][nl][N], for the inner product's own-digit rows)
     int int_epilogue;     // mode 3: integer (Shoup) epilogue for every limb (HYDIA_INT_EPILOGUE; default: FP64 for the limbs below 2^47)
     IpArgs ip;            // mode 4
     LoopAIp la;           // mode 5
@@ -305,6 +319,8 @@ void key_pack(hipStream_t st, const ModC *mod, int N, int nQ, int nT, int nd, co
 // the two halves of ntt15_inverse on their own (the fused key-switching tail runs the first pass of some rows elsewhere)
 void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t src_outer, size_t dst_outer, int X, const LimbSel &sel);
 void ntt15_inverse_p1(hipStream_t st, const NttTables &T, u64 *dst, size_t dst_outer, int X, const LimbSel &sel, const ScaleSel &scale);
+// inverse pass 2 of d2 = a1 b1 of a product (formed in the load; also stored to d2_out, compact [X][sel.n][N])
+void ntt15_inverse_p2_prod(hipStream_t st, const NttTables &T, const ProdSrc &ps, u64 *dst, size_t dst_outer, int X, const LimbSel &sel, u64 *d2_out);
 void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *acc_l, u64 *dst, size_t src_outer, size_t dst_outer, int XP, int l,
                                 u64 pinv, u64 pinv_sh, const u64 *addend, size_t add_x, size_t add_p, int dbl);
 // second pass of the ModUp forward transforms fused with the inner product (N = 2^15): dig holds pass-1 output of every

@@ -15,6 +15,7 @@
 #include <stdexcept>
 
 #include "kernels.h"
+#include "ntt_arith.h"  // FpA: exact FP64 products for the limbs below 2^47
 
 #include <algorithm>
 #include <cstdio>
@@ -192,6 +193,35 @@ __global__ __launch_bounds__(256) void k_lincomb_multi(const ModC *__restrict__ 
 #pragma unroll
     for (int t = 0; t < HY_LC_TERMS; t++)
         v[t] = t < lc.nterms ? *reinterpret_cast<const ulonglong2 *>(lc.src[t] + (size_t)xp * lc.ls[t] * N + i) : make_ulonglong2(0, 0);
+    if (lc.fp && M.ks + 2 <= 47) {
+        // limbs below 2^47 (round 4): exact FP64 products, v c - rint(v c / q) q (six instructions, no carries) instead of 128-bit
+        // multiply-accumulates and a Barrett reduction — the same canonical residues (|sum| < 8 x 0.8 q + q, exact in a double)
+        const FpA ar(M);
+        double vx[HY_LC_TERMS], vy[HY_LC_TERMS];
+#pragma unroll
+        for (int t = 0; t < HY_LC_TERMS; t++) {
+            vx[t] = FpA::u2d(v[t].x);
+            vy[t] = FpA::u2d(v[t].y);
+        }
+        for (int k = 0; k < lc.K; k++) {
+            const u64 *tb = lc.tab + (size_t)k * HY_LCM_BLOCK;
+            double ax = 0, ay = 0;
+#pragma unroll
+            for (int t = 0; t < HY_LC_TERMS; t++)
+                if (t < lc.nterms) {
+                    const FpA::TW W = ar.tw8(FpA::u2d(tb[t * HY_LC_LIMBS + j]));
+                    ax += ar.mulmod(vx[t], W);
+                    ay += ar.mulmod(vy[t], W);
+                }
+            if (p == 0) {
+                const double c0 = FpA::u2d(tb[HY_LC_TERMS * HY_LC_LIMBS + j]);
+                ax += c0;
+                ay += c0;
+            }
+            *reinterpret_cast<ulonglong2 *>(o + ((size_t)k * XP + xp) * nl * N + i) = make_ulonglong2(ar.fin_fwd(ax), ar.fin_fwd(ay));
+        }
+        return;
+    }
     for (int k = 0; k < lc.K; k++) {
         const u64 *tb = lc.tab + (size_t)k * HY_LCM_BLOCK;
         u128 ax = 0, ay = 0;

@@ -206,6 +206,35 @@ struct P2Pre {
     ulonglong2 sb0, sb1;            // subtrahend of mode 3
     bool has_ex, has_sb;
 };
+// operands of a fused product (ProdSrc) for four consecutive coefficients of one limb of one ciphertext: both polynomials of a and b
+struct P2Prod {
+    u64 a0[4], a1[4], b0[4], b1[4];
+    DEV static void ld4(const u64 *p, u64 (&o)[4]) {
+        const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(p), v = *reinterpret_cast<const ulonglong2 *>(p + 2);
+        o[0] = u.x; o[1] = u.y; o[2] = v.x; o[3] = v.y;
+    }
+    DEV void load(const ProdSrc &ps, int x, int j, unsigned idx) {
+        const u64 *pa = ps.a + (size_t)x * ps.a_x + (size_t)j * 32768 + idx, *pb = ps.b + (size_t)x * ps.b_x + (size_t)j * 32768 + idx;
+        ld4(pa, a0);
+        ld4(pa + ps.a_p, a1);
+        ld4(pb, b0);
+        ld4(pb + ps.b_p, b1);
+    }
+    // d_p of coefficient k as a small exact double (FP64 limbs) / as the canonical residue (any limb); p and k are compile-time in
+    // the unrolled callers
+    DEV double dp_fp(const FpA &ar, int p, int k) const {
+        if (p == 0) return ar.mulmod2(FpA::u2d(a0[k]), FpA::u2d(b0[k]));
+        return ar.mulmod2(FpA::u2d(a0[k]), FpA::u2d(b1[k])) + ar.mulmod2(FpA::u2d(a1[k]), FpA::u2d(b0[k]));
+    }
+    DEV u64 dp_int(const ModC &M, int p, int k) const {
+        if (p == 0) return mulmod(a0[k], b0[k], M);
+        return reduce128k((u128)a0[k] * b1[k] + (u128)a1[k] * b0[k], M);
+    }
+};
+// canonical a * b mod q in the arithmetic of the limb
+DEV u64 prod_canon(const FpA &ar, const ModC &, u64 a, u64 b) { return ar.fin_fwd(ar.mulmod2(FpA::u2d(a), FpA::u2d(b))); }
+DEV u64 prod_canon(const IntP &, const ModC &M, u64 a, u64 b) { return mulmod(a, b, M); }
+DEV u64 prod_canon(const IntA &, const ModC &M, u64 a, u64 b) { return mulmod(a, b, M); }
 // mode 5: the accumulator value of 4 consecutive coefficients of limb j, key polynomial p, rotation x — formed here instead of
 // being read back: nd lazy 128-bit products per coefficient, one reduction
 // The operands of one call: for every digit two pairs of digit residues and two pairs of key residues.  ALL of them are requested
@@ -367,15 +396,15 @@ DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned i
     }
     r.sb0 = r.sb1 = make_ulonglong2(0, 0);
     r.has_sb = false;
-    if (ST == 1 || ST == 3 || ST == 5) {
+    if (ST == 1 || ST == 3 || ST == 5 || ST == 9 || ST == 10) {
         const int x = xp >> 1, p = xp & 1;
-        if (st.addend && p < st.add_polys) {
+        if (st.addend && p < st.add_polys && ST != 9 && ST != 10) {
             const u64 *pa = st.addend + (size_t)x * st.add_x + (size_t)p * st.add_p + (size_t)j * N + idx;
             r.ex0 = *reinterpret_cast<const ulonglong2 *>(pa);
             r.ex1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
             r.has_ex = true;
         }
-        if (ST == 3 && st.sub) {
+        if ((ST == 3 || ST == 10) && st.sub) {
             const u64 *ps = st.sub + ((size_t)xp * st.sub_ls + j) * N + idx;
             r.sb0 = *reinterpret_cast<const ulonglong2 *>(ps);
             r.sb1 = *reinterpret_cast<const ulonglong2 *>(ps + 2);
@@ -392,19 +421,25 @@ DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned i
     return r;
 }
 template <int ST>
-DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned idx, const u64 v[4], const P2Pre &pre) {
+DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned idx, const u64 v[4], const P2Pre &pre, const P2Prod &po) {
     constexpr size_t N = 32768;
     const u64 q = M.q, mul = st.mul.s[j], muls = st.mul.s_sh[j];
     const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
-    const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
+    u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
     u64 r[4];
-    if (ST == 3) {  // ((in P^{-1} + addend)(x2) - v) q_l^{-1} (- sub)(+ addc): ModDown and Rescale in one epilogue
+    bool has_ex = pre.has_ex;
+    if (ST == 9 || ST == 10) {  // the addend is the product's d_p, formed here
+#pragma unroll
+        for (int k = 0; k < 4; k++) ev[k] = po.dp_int(M, xp & 1, k);
+        has_ex = true;
+    }
+    if (ST == 3 || ST == 9 || ST == 10) {  // ((in P^{-1} + addend)(x2) - v) q_l^{-1} (- sub)(+ addc): ModDown and Rescale in one epilogue
         const u64 m2 = st.mul2.s[j], m2s = st.mul2.s_sh[j];
         const u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u64 t = mulmod_shoup(iv[k], mul, muls, q);
-            if (pre.has_ex) t = addmod(t, ev[k], q);
+            if (has_ex) t = addmod(t, ev[k], q);
             if (st.dbl) t = addmod(t, t, q);
             t = mulmod_shoup(submod(t, v[k], q), m2, m2s, q);
             if (pre.has_sb) t = st.sub_add ? addmod(t, sv[k], q) : submod(t, sv[k], q);
@@ -467,8 +502,7 @@ struct Epi3Fp {
         return Epi3Fp{};
     }
 };
-template <>
-DEV Epi3Fp Epi3Fp::make<3, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) {
+DEV Epi3Fp epi3fp_make(const NttStore &st, const FpA &ar, const ModC &M, int j) {
     Epi3Fp e;
     const u64 m2 = st.mul2.s[j];
     const u64 two = st.dbl ? addmod(m2, m2, M.q) : m2;  // (x2) q_l^{-1}
@@ -478,7 +512,15 @@ DEV Epi3Fp Epi3Fp::make<3, FpA>(const NttStore &st, const FpA &ar, const ModC &M
     e.addc = st.has_addc ? FpA::u2d(st.addc[j]) : 0.0;
     return e;
 }
-DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigned idx, const double (&v)[4], const P2Pre &pre, const Epi3Fp &e) {
+template <>
+DEV Epi3Fp Epi3Fp::make<3, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
+template <>
+DEV Epi3Fp Epi3Fp::make<9, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
+template <>
+DEV Epi3Fp Epi3Fp::make<10, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
+template <bool PROD>
+DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigned idx, const double (&v)[4], const P2Pre &pre, const Epi3Fp &e,
+                       const P2Prod &po) {
     constexpr size_t N = 32768;
     const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
     const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
@@ -488,7 +530,8 @@ DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigne
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         double t = ar.mulmod(FpA::u2d(iv[k]), e.k1) - ar.mulmod(v[k], e.k3);
-        if (pre.has_ex) t += ar.mulmod(FpA::u2d(ev[k]), e.k2);
+        if (PROD) t += ar.mulmod(po.dp_fp(ar, xp & 1, k), e.k2);
+        else if (pre.has_ex) t += ar.mulmod(FpA::u2d(ev[k]), e.k2);
         if (pre.has_sb) t += st.sub_add ? FpA::u2d(sv[k]) : -FpA::u2d(sv[k]);
         if (addc) t += e.addc;
         r[k] = ar.fin_fwd(t);
@@ -497,8 +540,8 @@ DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigne
     *reinterpret_cast<ulonglong2 *>(o3 + idx) = make_ulonglong2(r[0], r[1]);
     *reinterpret_cast<ulonglong2 *>(o3 + idx + 2) = make_ulonglong2(r[2], r[3]);
 }
-template <class A>
-DEV void p2_finish3_fp(const NttStore &, const A &, int, int, unsigned, const typename A::T (&)[4], const P2Pre &, const Epi3Fp &) {}
+template <bool PROD, class A>
+DEV void p2_finish3_fp(const NttStore &, const A &, int, int, unsigned, const typename A::T (&)[4], const P2Pre &, const Epi3Fp &, const P2Prod &) {}
 
 // The LDS image of a pass-2 workgroup: 8 blocks x 8 rows x 32 coefficients per polynomial.  Padded (rows of 36: phase B's (row, 4k + b)
 // accesses of a half-wave hit 32 distinct bank pairs) or, SWZ, unpadded with the position XOR-ed by 4 x row — the same property at
@@ -650,14 +693,16 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         }
         // the merged epilogues' operands are fetched one half at a time (the second half's while the first half is finished): 109 / 120
         // instead of 136 / 150 registers, i.e. 4 instead of 3 waves per SIMD (-0.4 ms per query at 2^14, -0.8 ms at 2^20)
-        constexpr bool SPLIT = ST == 5 || ST == 3;
+        constexpr bool SPLIT = ST == 5 || ST == 3 || ST == 9 || ST == 10;  // (9, 10 = 3 with the addend formed from a fused product: no `ex` operand; 9 has no `sub` operand either — 126 registers, four waves per SIMD)
         const Epi3Fp epi = Epi3Fp::make<ST, A>(stp, ar, M, slot);
         P2Pre pre[2][NP];
+        P2Prod po;  // mode 3 with a fused product: a0, a1, b0, b1 of the ciphertext (shared by its two polynomials when NP = 2)
         if (ST != 0 && ST != 4 && ST != 6) {
 #pragma unroll
             for (int hh = 0; hh < (SPLIT ? 1 : 2); hh++)
 #pragma unroll
                 for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh), M);
+            if (ST == 9 || ST == 10) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t));
         }
         __syncthreads();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
@@ -673,6 +718,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             if (SPLIT && hh == 1) {
 #pragma unroll
                 for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024), M);
+                if (ST == 9 || ST == 10) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t + 1024));
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) {
@@ -698,12 +744,12 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     o1.x = ar.fin_fwd(c2); o1.y = ar.fin_fwd(c3);
                     *reinterpret_cast<ulonglong2 *>(d[p] + e) = o0;
                     *reinterpret_cast<ulonglong2 *>(d[p] + e + 2) = o1;
-                } else if (ST == 3 && std::is_same<A, FpA>::value && !stp.int_epilogue) {
+                } else if ((ST == 3 || ST == 9 || ST == 10) && std::is_same<A, FpA>::value && !stp.int_epilogue) {
                     const T cv[4] = {c0, c1, c2, c3};
-                    p2_finish3_fp(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi);
+                    p2_finish3_fp<ST == 9 || ST == 10>(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi, po);
                 } else {
                     const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
-                    p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[SPLIT ? 0 : hh][p]);
+                    p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[SPLIT ? 0 : hh][p], po);
                 }
             }
             if (ST == 4 || ST == 6) {
@@ -726,9 +772,17 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                         IpAcc<A> *ip = pp == 0 ? ipb : ipa;
                         u64 f4[4] = {ip[0].fin(ar, M, NP + 1), ip[1].fin(ar, M, NP + 1), ip[2].fin(ar, M, NP + 1), ip[3].fin(ar, M, NP + 1)};
                         if (ip_t == stp.ip.drop_l) {  // workgroup-uniform: the limb the rescale drops — (sum P^{-1} + d_l)(x2), k_moddown_last_limb's arithmetic
-                            const u64 *pa = stp.ip.drop_add + (size_t)xp0 * stp.ip.drop_add_x + (size_t)pp * stp.ip.drop_add_p + (size_t)ip_t * 32768 + ci;
-                            const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(pa), d1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
-                            const u64 dv[4] = {d0.x, d0.y, d1.x, d1.y};
+                            u64 dv[4];
+                            if (stp.ip.drop_has_prod) {  // d_p of the fused product at this limb
+                                P2Prod dp;
+                                dp.load(stp.ip.drop_prod, xp0, ip_t, (unsigned)ci);
+#pragma unroll
+                                for (int k = 0; k < 4; k++) dv[k] = dp.dp_int(M, pp, k);
+                            } else {
+                                const u64 *pa = stp.ip.drop_add + (size_t)xp0 * stp.ip.drop_add_x + (size_t)pp * stp.ip.drop_add_p + (size_t)ip_t * 32768 + ci;
+                                const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(pa), d1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
+                                dv[0] = d0.x; dv[1] = d0.y; dv[2] = d1.x; dv[3] = d1.y;
+                            }
                             const u64 qq = M.q;
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
@@ -785,6 +839,17 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                         i0.x = addmod(i0.x, i0.x, qq); i0.y = addmod(i0.y, i0.y, qq);
                         i1.x = addmod(i1.x, i1.x, qq); i1.y = addmod(i1.y, i1.y, qq);
                     }
+                } else if (ST == 8) {  // ... is d2 = a1 b1 of a fused product (ProdSrc); also kept for the inner product's own-digit rows
+                    const int xq = xp0 + p;
+                    const size_t off = (size_t)slot * 32768 + (size_t)(B0 + e);
+                    const u64 *pa = stp.prod.a + (size_t)xq * stp.prod.a_x + stp.prod.a_p + off, *pb = stp.prod.b + (size_t)xq * stp.prod.b_x + stp.prod.b_p + off;
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(pa), a1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
+                    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(pb), b1 = *reinterpret_cast<const ulonglong2 *>(pb + 2);
+                    i0 = make_ulonglong2(prod_canon(ar, M, a0.x, b0.x), prod_canon(ar, M, a0.y, b0.y));
+                    i1 = make_ulonglong2(prod_canon(ar, M, a1.x, b1.x), prod_canon(ar, M, a1.y, b1.y));
+                    u64 *po2 = stp.out + ((size_t)xq * stp.nl) * 32768 + off;
+                    *reinterpret_cast<ulonglong2 *>(po2) = i0;
+                    *reinterpret_cast<ulonglong2 *>(po2 + 2) = i1;
                 } else {
                     i0 = *reinterpret_cast<const ulonglong2 *>(s[p] + e);
                     i1 = *reinterpret_cast<const ulonglong2 *>(s[p] + e + 2);
@@ -1084,7 +1149,7 @@ __global__ __launch_bounds__(1024) void k_ntt15_1p(NttTables T, const ulonglong2
                         *reinterpret_cast<ulonglong2 *>(d + 4 * gi) = make_ulonglong2(vv[0], vv[1]);
                         *reinterpret_cast<ulonglong2 *>(d + 4 * gi + 2) = make_ulonglong2(vv[2], vv[3]);
                     } else {
-                        p2_finish<ST>(stp, M, xp, slot, (unsigned)(4 * gi), vv, pre);
+                        p2_finish<ST>(stp, M, xp, slot, (unsigned)(4 * gi), vv, pre, P2Prod{});  // (the one-pass kernel takes no fused product)
                         pre = nxt;
                     }
                 }
@@ -1209,6 +1274,8 @@ bool ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
             stp.ip.drop_add = drop->add;
             stp.ip.drop_add_x = drop->add_x;
             stp.ip.drop_add_p = drop->add_p;
+            stp.ip.drop_has_prod = drop->prod ? 1 : 0;
+            if (drop->prod) stp.ip.drop_prod = *drop->prod;
         }
         snprintf(name, sizeof name, "k_ntt15_p2_ip_all<%d>", nd);
         ledger_add(name, bytes_q + bytes_p);
@@ -1299,7 +1366,7 @@ static void launch_1p(hipStream_t st, const NttTables &T, const u64 *src, u64 *d
     {
         char name[64];
         snprintf(name, sizeof name, "k_ntt15_1p<%s, %d, %d>", INV ? "true" : "false", LD, ST);
-        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * nitems * 262144.0);
+        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : ST == 9 ? 3.0 : ST == 10 ? 4.0 : 0.0)) * nitems * 262144.0);
     }
     hipLaunchKernelGGL((k_ntt15_1p<INV, LD, ST>), dim3(nitems), dim3(1024), OP_LDS_ELEMS * sizeof(u64), st, T,
                        INV ? T.itwf : T.twf, INV ? T.itwd : T.twd, T.mod, src, dst, so, dso, sel, slot0, X, nitems, scale, ld, stp);
@@ -1321,7 +1388,7 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
     {   // pass-1 output in, result out, + the epilogue's operands: acc & addend (1), rescale input (2), both + subtrahend (3)
         char name[64];
         snprintf(name, sizeof name, "k_ntt15_p2<false, %d, %d>", pair_polys(X, nsl) ? 2 : 1, ST);
-        double per = (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : 0.0)) * 262144.0;
+        double per = (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : ST == 9 ? 3.0 : ST == 10 ? 4.0 : 0.0)) * 262144.0;
         if (ST == 5)  // pass-1 output in, result out, addend on every other polynomial, nd key rows (6- or 8-byte residues); digits from L2
             per = 2.5 * 262144.0 + stp.la.nd * 32768.0 * (stp.la.packed_nQ > 0 ? (6.0 * (nsl - 1) + 8.0) / nsl : 8.0);
         ledger_add(name, per * X * nsl);
@@ -1369,6 +1436,8 @@ void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t
     if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 5) launch_p2_fwd<5>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else if (stp.mode == 3 && stp.has_prod && stp.sub) launch_p2_fwd<10>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else if (stp.mode == 3 && stp.has_prod) launch_p2_fwd<9>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else launch_p2_fwd<0>(st, T, dst, dso, X, sel, 0, sel.n, stp);
 }
@@ -1415,6 +1484,20 @@ void ntt15_inverse_p2(hipStream_t st, const NttTables &T, const u64 *src, u64 *d
         hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, 0, sel.n, stp);
     else
         hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * sel.n), dim3(256), 0, st, T, src, dst, so, dso, sel, 0, sel.n, stp);
+}
+void ntt15_inverse_p2_prod(hipStream_t st, const NttTables &T, const ProdSrc &ps, u64 *dst, size_t dso, int X, const LimbSel &sel, u64 *d2_out) {
+    NttStore stp{};
+    stp.mode = 8;
+    stp.has_prod = 1;
+    stp.prod = ps;
+    stp.out = d2_out;
+    stp.nl = sel.n;
+    const bool pair = pair_polys(X, sel.n);
+    ledger_add(pair ? "k_ntt15_p2<true, 2, 8>" : "k_ntt15_p2<true, 1, 8>", 4.0 * X * sel.n * 262144.0);  // a1, b1 in; d2 and the raw image out
+    if (pair)
+        hipLaunchKernelGGL((k_ntt15_p2<true, 2, 8>), dim3(16, (X / 2) * sel.n), dim3(256), 0, st, T, (const u64 *)nullptr, dst, (size_t)0, dso, sel, 0, sel.n, stp);
+    else
+        hipLaunchKernelGGL((k_ntt15_p2<true, 1, 8>), dim3(16, X * sel.n), dim3(256), 0, st, T, (const u64 *)nullptr, dst, (size_t)0, dso, sel, 0, sel.n, stp);
 }
 // first inverse pass of limb l of (acc P^{-1} + addend)(x2) — k_moddown_last_limb's arithmetic in the load (relin + rescale tail)
 void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *acc_l, u64 *dst, size_t so, size_t dso, int XP, int l,
