@@ -456,12 +456,58 @@ void Context::build_rotptrs() {
     rotptrs_valid = true;
 }
 
+void Context::ks_fused(const u64 *c1, size_t c1_xs, int X, int nl, const u64 *key, const u64 *const *d_key_cell, const u64 *const *d_keys,
+                       const u64 *addend, size_t add_x, size_t add_p, int add_polys, const unsigned *d_ginv, int same_g, bool dbl, u64 *out) {
+    const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, XP = 2 * X;
+    const LimbSel qsel = sel_q(nl), psel = sel_range(nQ, nT);
+    u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
+    modup_digits(c1, c1_xs, X, nl, dig, /*copy_own=*/false, /*p1_only=*/true);
+    u64 *acc = pool.get((size_t)XP * nE * N * sizeof(u64));
+    u64 *y = pool.get((size_t)XP * nP * N * sizeof(u64));  // raw image of the special-prime sums' inverse pass 2'
+    timer_begin("ks_inner_product");
+    hk::ntt15_p2_inner_product(stream, tabs, d_mod, dig, (size_t)nd * nE * N, nd, X, nl, nP, nT, alpha, d_keys ? d_keys : d_key_cell, key, c1, c1_xs, acc,
+                               y, (size_t)nP * N, 0, nullptr, d_keys != nullptr);
+    timer_end("ks_inner_product");
+    pool.put(dig);
+    const CfPlan &cp = cf_plan_moddown(nl, false);
+    const bool small = hk::ntt15_colfuse_small(XP, 1);
+    if (small) hk::ntt15_inverse_p1(stream, tabs, y, (size_t)nP * N, XP, psel, scale_of(psel, Phat_inv, true));
+    u64 *conv = pool.get((size_t)XP * nl * N * sizeof(u64));
+    hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, XP, cp.dev, cp.host.data(), 1, small);
+    pool.put(y);
+    std::vector<u64> pinv(Pinv_mod_q.begin(), Pinv_mod_q.begin() + nl);
+    NttStore stp{};
+    stp.mode = 1;
+    stp.out = out;
+    stp.nl = nl;
+    stp.in = acc;
+    stp.in_ls = nE;
+    stp.mul = scale_of(qsel, pinv, false);
+    stp.addend = addend;
+    stp.add_x = add_x;
+    stp.add_p = add_p;
+    stp.add_polys = add_polys;
+    stp.dbl = dbl ? 1 : 0;
+    stp.ginv = d_ginv;
+    stp.same_g = same_g;
+    hk::ntt15_forward_p2_fused(stream, tabs, conv, (size_t)nl * N, XP, qsel, stp);
+    pool.put(conv);
+    pool.put(acc);
+}
+
 // RelinearizeInPlace (sender_diag.cpp:79)
 void Context::relinearize(Ct &c, bool dbl) {
     if (c.npoly != 3) return;
     if (!relin_key.d) throw StateError("hydia: relinearisation key not loaded");
     const int nl = c.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X;
     op_bytes("op:relinearize", N, (double)X * (nd * nE + 2 * nP + 2 * nl), (double)nd * 2 * nE * N * 8);
+    if (ks_fused_ok()) {
+        Ct out(this, X, 2, nl, c.scale);
+        ks_fused(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, relin_key.d, relin_key.d_cell, nullptr, c.d, c.ct_elems(), c.poly_elems(), 2, nullptr, 0, dbl,
+                 out.d);
+        c = std::move(out);
+        return;
+    }
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(c.d + 2 * c.poly_elems(), c.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, c.scale);
@@ -813,6 +859,12 @@ Ct Context::rotate(const Ct &a, int rot) {
     if (it == rot_keys.end()) throw StateError("hydia: rotation key " + std::to_string(rot) + " not loaded");
     const int nl = a.nl, nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = a.X;
     op_bytes("op:rotate", N, (double)X * (nd * nE + 2 * nP + 2 * nl), (double)nd * 2 * nE * N * 8 + 4.0 * X * nl * N * 8);
+    if (ks_fused_ok()) {
+        Ct out(this, X, 2, nl, a.scale);
+        ks_fused(a.d + a.poly_elems(), a.ct_elems(), X, nl, it->second.d, it->second.d_cell, nullptr, a.d, a.ct_elems(), a.poly_elems(), 1, it->second.d_gal + 1, 1,
+                 false, out.d);
+        return out;
+    }
     u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
     modup_digits(a.d + a.poly_elems(), a.ct_elems(), X, nl, dig);
     Ct out(this, X, 2, nl, a.scale);
@@ -942,11 +994,15 @@ Ct Context::similarity_bsgs_sum(const Ct &qc) {
         const size_t ce = acc.ct_elems();
         op_bytes("op:rotate", N, (double)X * (nd * nE + 2 * nP + 2 * nl), (double)(NG - 1) * nd * 2 * nE * N * 8 + 4.0 * X * nl * N * 8);
         Ct rotd(this, X, 2, nl, acc.scale);
-        u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
         const u64 *c = acc.d + (size_t)G * ce;
-        modup_digits(c + acc.poly_elems(), ce, X, nl, dig);
-        ks_apply(dig, (size_t)nd * nE * N, X, nl, d_giant_keys, 0, c, ce, acc.poly_elems(), 1, d_giant_gal, d_giant_ginv, 0, false, rotd.d);
-        pool.put(dig);
+        if (ks_fused_ok()) {
+            ks_fused(c + acc.poly_elems(), ce, X, nl, nullptr, nullptr, d_giant_keys, c, ce, acc.poly_elems(), 1, d_giant_ginv, 0, false, rotd.d);
+        } else {
+            u64 *dig = pool.get((size_t)X * nd * nE * N * sizeof(u64));
+            modup_digits(c + acc.poly_elems(), ce, X, nl, dig);
+            ks_apply(dig, (size_t)nd * nE * N, X, nl, d_giant_keys, 0, c, ce, acc.poly_elems(), 1, d_giant_gal, d_giant_ginv, 0, false, rotd.d);
+            pool.put(dig);
+        }
         HIP_CHECK(hipMemcpyAsync(acc.d + (size_t)G * ce, rotd.d, (size_t)X * ce * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     }
     op_bytes("op:add", N, 0, (double)(NG + 1) * G * 2 * nl * N * 8);

@@ -274,6 +274,14 @@ struct Context : HostParams {
     // the dropped limb of the ModDown output is obtained in the coefficient domain, so ModDown's and Rescale's
     // corrections share a single forward NTT per remaining limb ((l+1) transforms per polynomial saved)
     void relin_rescale(Ct &c, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
+    // hybrid key switch of one polynomial per ciphertext through the fused pipeline (round 4: what relin_rescale_into does without its
+    // rescale half): ModUp with the digits' second pass inside the inner product, the special-prime sums straight into the inverse
+    // transform, column-fused ModDown conversion, combine (+ addend, doubling, automorphism) in the last pass.  key: one key for every
+    // ciphertext, or d_keys (device array) one per ciphertext.  false: not available here (generic rings, switches) — use ks_apply
+    bool ks_fused_ok() const { return prm.logN == 15 && fuse_ip && !relin_separate_intt && cf_ok() && ks_fuse; }
+    bool ks_fuse = true;  // HYDIA_NO_KS_FUSE: relinearize / rotate / giant steps through modup_digits + ks_apply (round 3's form)
+    void ks_fused(const u64 *c1, size_t c1_xs, int X, int nl, const u64 *key, const u64 *const *d_key_cell, const u64 *const *d_keys,
+                  const u64 *addend, size_t add_x, size_t add_p, int add_polys, const unsigned *d_ginv, int same_g, bool dbl, u64 *out);
     // ps != nullptr: c carries shape and scale only (X, nl, scale; no data) — the degree-2 ciphertext is the product ps and is never formed
     void relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps = nullptr);
     // (a b) relinearised (doubled) and rescaled (+- sub)(+ addc): EvalMultNoRelin + relin_rescale, with the tensor fused into its

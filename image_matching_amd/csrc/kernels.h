@@ -86,6 +86,7 @@ struct ProdSrc {
 };
 struct IpArgs {
     const u64 *key;   // [nd][2][nT][N]
+    const u64 *const *keys;  // non-null (device array): ciphertext x takes keys[x] instead (giant-step rotations: one key per giant step)
     int nT, nE, nl, alpha;
     int own;          // 1: limbs t < nl also take their own digit's residues (evaluation form) from c2
     const u64 *c2;    // [x][..][N] the polynomial being key-switched, limb t at c2 + x*c2_xs + t*N
@@ -329,7 +330,7 @@ void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *a
 // returns true when the launch also produced the dropped limb's inverse-pass-2 image (`drop` given and the merged kernel ran)
 bool ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dig_x_stride, int nd, int X,
                             int nl, int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
-                            u64 *inv_out = nullptr, size_t inv_outer = 0, int inv_row0 = 0, const DropLimb *drop = nullptr);
+                            u64 *inv_out = nullptr, size_t inv_outer = 0, int inv_row0 = 0, const DropLimb *drop = nullptr, bool per_x_keys = false);
 void ntt15_forward_p1(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst, size_t so, size_t dso, int X, const LimbSel &sel);
 // second pass alone, in place on pass-1 output (plain store)
 void ntt15_forward_p2(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel);

@@ -713,6 +713,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
             // mode 4: lazy 128-bit sums of value * key over the digits this workgroup transforms (+ the limb's own digit)
             IpAcc<A> ipb[4], ipa[4];
+            const u64 *const ip_key = (ST == 4 || ST == 6) ? (stp.ip.keys ? stp.ip.keys[xp0] : stp.ip.key) : nullptr;  // one key, or one per ciphertext
             const int ip_t = slot, ip_m = ip_t < stp.ip.nl ? ip_t : stp.ip.nT - stp.ip.nE + ip_t;
             const int ip_own = (stp.ip.own && ip_t < stp.ip.nl) ? ip_t / stp.ip.alpha : (1 << 30);
             if (SPLIT && hh == 1) {
@@ -732,7 +733,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 if (ST == 4 || ST == 6) {
                     const typename IpAcc<A>::V vv[4] = {IpAcc<A>::prep(ar, c0), IpAcc<A>::prep(ar, c1), IpAcc<A>::prep(ar, c2), IpAcc<A>::prep(ar, c3)};
                     const int dgt = p >= ip_own ? p + 1 : p;
-                    const u64 *kb = stp.ip.key + (((size_t)dgt * 2) * stp.ip.nT + ip_m) * 32768 + (B0 + e);
+                    const u64 *kb = ip_key + (((size_t)dgt * 2) * stp.ip.nT + ip_m) * 32768 + (B0 + e);
                     const u64 *ka = kb + (size_t)stp.ip.nT * 32768;
                     const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(kb), b1 = *reinterpret_cast<const ulonglong2 *>(kb + 2);
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ka), a1 = *reinterpret_cast<const ulonglong2 *>(ka + 2);
@@ -756,7 +757,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 const size_t ci = (size_t)(B0 + e);
                 if (ip_own < (1 << 30)) {
                     const u64 *cv = stp.ip.c2 + (size_t)xp0 * stp.ip.c2_xs + (size_t)ip_t * 32768 + ci;
-                    const u64 *kb = stp.ip.key + (((size_t)ip_own * 2) * stp.ip.nT + ip_m) * 32768 + ci;
+                    const u64 *kb = ip_key + (((size_t)ip_own * 2) * stp.ip.nT + ip_m) * 32768 + ci;
                     const u64 *ka = kb + (size_t)stp.ip.nT * 32768;
                     const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(cv), v1 = *reinterpret_cast<const ulonglong2 *>(cv + 2);
                     const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(kb), b1 = *reinterpret_cast<const ulonglong2 *>(kb + 2);
@@ -1243,11 +1244,12 @@ namespace hk {
 
 bool ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod, const u64 *dig, size_t dxs, int nd, int X, int nl,
                             int nP, int nT, int alpha, const u64 *const *keys, const u64 *key, const u64 *c2, size_t c2_xs, u64 *acc,
-                            u64 *inv_out, size_t inv_outer, int inv_row0, const DropLimb *drop) {
+                            u64 *inv_out, size_t inv_outer, int inv_row0, const DropLimb *drop, bool per_x_keys) {
     const int nE = nl + nP;
     NttStore stp{};
     stp.mode = 4;
     stp.ip.key = key;
+    stp.ip.keys = per_x_keys ? keys : nullptr;  // device array: the key of ciphertext x (giant steps); else `key` serves every x
     stp.ip.nT = nT;
     stp.ip.nE = nE;
     stp.ip.nl = nl;
@@ -1297,7 +1299,7 @@ bool ntt15_p2_inner_product(hipStream_t st, const NttTables &T, const ModC *mod,
         LimbSel qs{};
         qs.n = nl;
         for (int j = 0; j < nl; j++) qs.mod[j] = j;
-        inner_product(st, mod, 32768, dig, dxs, nd, keys, 1, nT, acc, X, qs, c2, c2_xs, alpha, nl, nE);
+        inner_product(st, mod, 32768, dig, dxs, nd, keys, per_x_keys ? 0 : 1, nT, acc, X, qs, c2, c2_xs, alpha, nl, nE);
     } else if (nd == 2) {
         hipLaunchKernelGGL((k_ntt15_p2_ip<1, true>), dim3(16, nl * X), dim3(256), 0, st, T, dig, dxs, X, 0, stp);
     } else if (nd == 3) {
