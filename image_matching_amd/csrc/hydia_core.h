@@ -175,11 +175,11 @@ struct Context : HostParams {
         while (B * B < prm.dim) B <<= 1;
         return B;
     }
-    // measured on MI355X (profiles/r03/matvec_sweep.txt: every split at 1 .. 32 blocks): a baby costs ~12 us per query, a giant step
-    // (relinearisation or rotation of one partial sum) ~30 us per block — 64 babies win up to 3 blocks, 128 up to 12, 256 up to 24
+    // measured on MI355X (profiles/r04/matvec_sweep.txt: every split at 1 .. 64 blocks, after the giant steps moved to the fused key
+    // switch): 64 babies win up to 3 blocks, 128 up to 12, 256 up to 40 (24 in round 3), all hoisted above
     int auto_babies(size_t blocks) const {
         const int base = bsgs_babies();
-        static const struct { size_t limit; int mult; } rule[] = {{3, 2}, {12, 4}, {24, 8}};  // 64 / 128 / 256 babies at dim 512
+        static const struct { size_t limit; int mult; } rule[] = {{3, 2}, {12, 4}, {40, 8}};  // 64 / 128 / 256 babies at dim 512
         for (const auto &r : rule)
             if (blocks <= r.limit) return std::min(prm.dim, base * r.mult);
         return prm.dim;

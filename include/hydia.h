@@ -155,7 +155,7 @@ int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t se
  *   any power of two dividing vector_dim in between
  * Decrypted results agree within CKKS noise (1e-4 on scores) whatever B; ciphertexts are bit-identical between runs with the same B.
  * hydia_set_matvec mode: 0 auto (hydia_auto_babies: B grows with the blocks the enrolling context holds — at vector_dim 512: 64 up
- * to 3 blocks, 128 up to 12, 256 up to 24, hoisted above; measured, profiles/r03/matvec_sweep.txt), 1 hoisted, otherwise B itself; initial value from HYDIA_MATVEC=auto|hoisted|bsgs|<B>.
+ * to 3 blocks, 128 up to 12, 256 up to 40, hoisted above; measured, profiles/r04/matvec_sweep.txt), 1 hoisted, otherwise B itself; initial value from HYDIA_MATVEC=auto|hoisted|bsgs|<B>.
  * It takes effect at the NEXT enrolment; hydia_db_kind / hydia_db_babies tell what is resident (kind 0 none, 5 hoisted diagonals,
  * 6 pre-rotated diagonals, 4 HERS columns).  Ciphertexts imported one by one (hydia_db_alloc + hydia_db_import_ct: the reference
  * enroller's) are taken as hoisted unless hydia_db_set_babies says otherwise (a database of more than 8 blocks is then re-ordered in

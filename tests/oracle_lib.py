@@ -19,7 +19,7 @@ def auto_babies(dim, blocks):
     base = 1
     while base * base < dim:
         base *= 2
-    for limit, mult in ((3, 2), (12, 4), (24, 8)):
+    for limit, mult in ((3, 2), (12, 4), (40, 8)):
         if blocks <= limit:
             return min(dim, base * mult)
     return dim

@@ -124,7 +124,7 @@ def test_three_block_sender_bit_exact_full_ring(im, full, matvec):
                                                                (10, "hoisted", 512, 2, "sim")])
 def test_auto_tiers_and_headline_kernel_bit_exact_full_ring(im, full, blocks, matvec, babies, group, checks):
     """Round-3 review: the auto rule's 128-baby (4-12 blocks: what BASELINE config 4's database and every 8-block shard of config 5
-    get) and 256-baby (13-24 blocks) splits were compared with the oracle nowhere, and the headline loop-B kernel (k_hydia_tensor24 on
+    get) and 256-baby (13-40 blocks) splits were compared with the oracle nowhere, and the headline loop-B kernel (k_hydia_tensor24 on
     the group-sequential layout, hoisted databases of more than 8 blocks) only at N = 2^11.  Here at N = 2^15 / dim 512 on ragged
     databases: similarity, index and membership ciphertexts equal the oracle's restatement of the same split, bit for bit."""
     P, K, Or, cc = full
