@@ -179,10 +179,10 @@ DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 // residues below 2^60 with constants below q).
 template <class A, bool MDR>
 DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
-                    unsigned neg, typename A::T (&v)[16]) {
+                    unsigned neg, typename A::T (&v)[16], bool nosrc) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u64 r = reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f).wide(), M);
+        u64 r = nosrc ? 0 : reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f).wide(), M);
         if (MDR) {
             const u64 c = reduce64(um[k * 256], M);
             r = addmod(r, ((neg >> k) & 1u) ? negmod(c, M.q) : c, M.q);
@@ -192,10 +192,10 @@ DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[
 }
 template <bool MDR>
 DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
-                    unsigned neg, double c60, double (&v)[16]) {
+                    unsigned neg, double c60, double (&v)[16], bool nosrc) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        double r = cf_fold(ar, cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f), c60);
+        double r = nosrc ? 0.0 : cf_fold(ar, cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f), c60);
         if (MDR) {
             const double c = FpA::u2d(um[k * 256]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
             r += ((neg >> k) & 1u) ? -c : c;
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         for (int s = 0; s < HY_CF_SRC; s++) fl.set(s, s < cf.nk ? cf.fl[s] : 0);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const u64 yl = submod(umem[k * 256], reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], fl).wide(), Ml), Ml.q);  // own slot: no barrier needed
+            const u64 yl = cf.nk == 0 ? umem[k * 256]  // a plain Rescale: the dropped limb itself
+                                      : submod(umem[k * 256], reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], fl).wide(), Ml), Ml.q);  // own slot: no barrier needed
             const bool ng = yl > half;
             umem[k * 256] = ng ? Ml.q - yl : yl;
             neg |= (ng ? 1u : 0u) << k;
@@ -315,17 +316,17 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         if (fp) {
             const FpA ar(M);
             double v[16];
-            cf_convert<MDR>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v);
+            cf_convert<MDR>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v, MDR && cf.nk == 0);
             cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
         } else if ((T.pm_mask >> m) & 1u) {
             const IntP ar(M);
             u64 v[16];
-            cf_convert<IntP, MDR>(ar, M, f, y, umem, neg, v);
+            cf_convert<IntP, MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
             cf_forward<IntP>(ar, tw, ltw, lds, g, col, v, d);
         } else {
             const IntA ar(M);
             u64 v[16];
-            cf_convert<IntA, MDR>(ar, M, f, y, umem, neg, v);
+            cf_convert<IntA, MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
             cf_forward<IntA>(ar, tw, ltw, lds, g, col, v, d);
         }
     }

@@ -182,6 +182,32 @@ const Context::CfPlan &Context::cf_plan_moddown_rescale(int nl, bool dbl) {
     return cf_plan_store(key, std::move(maps));
 }
 
+// Rescale from level nl (l = nl - 1 dropped) as a column-fused map: no conversion sources, the dropped limb u (row 0, N^{-1}) is
+// centred and spread to limbs 0..l-1 — pass 1' of u, the spread and pass 1 of every target in one launch
+const Context::CfPlan &Context::cf_plan_rescale(int nl) {
+    const std::string key = "rs:" + std::to_string(nl);
+    auto it = cf_plans.find(key);
+    if (it != cf_plans.end()) return it->second;
+    const int l = nl - 1;
+    if (l > HY_CF_TGT) throw std::runtime_error("hydia: too many targets for the column-fused conversion");
+    std::vector<ColFuse> maps(1);
+    ColFuse &cf = maps[0];
+    cf = ColFuse{};
+    cf.nk = 0;
+    cf.nt = l;
+    cf.mdr = 1;
+    cf.l = l;
+    cf.umod = l;
+    cf.urow = 0;
+    cf.usc = mod[l].ninv;
+    cf.usc_sh = mod[l].ninv_sh;
+    for (int j = 0; j < l; j++) {
+        cf.tmod[j] = j;
+        cf.trow[j] = j;
+    }
+    return cf_plan_store(key, std::move(maps));
+}
+
 // ModUp of hybrid key switching: for each digit d (limbs [d*alpha, min((d+1)alpha, nl))) the digit's residues are
 // extended to every other limb of Q_l u P by fast base conversion.  The (D/q_j)^{-1} factors ride on the inverse
 // NTT's N^{-1} scaling, so the conversion kernel is a pure lazy multiply-accumulate.  One inverse transform and one conversion
@@ -524,11 +550,37 @@ void Context::rescale(Ct &c, const Ct *sub, const double *addc) {
     op_bytes("op:rescale", N, (double)XP * nl, 0);
     u64 *t = pool.get((size_t)XP * N * sizeof(u64));
     const LimbSel last = sel_range(l, l + 1);
-    ntt_inv(c.d + (size_t)l * N, t, c.poly_elems(), (size_t)N, XP, last, scale_ninv(last));
     u64 *tmp = pool.get((size_t)XP * l * N * sizeof(u64));
     const LimbSel qsel = sel_q(l);
     Ct out(this, c.X, c.npoly, l, c.scale / (double)q[l]);
     std::vector<u64> qi(ql_inv[l].begin(), ql_inv[l].begin() + l);
+    // (round 4) batches that fill the chip: inverse pass 2' of the dropped limb, then ONE column-fused launch (pass 1', centring,
+    // spread, pass 1 of every remaining limb; u is read once instead of once per limb), then the combine in pass 2
+    const bool rcf = rescale_cf && cf_ok() && l <= HY_LC_LIMBS && l <= HY_CF_TGT && (q[l] >> 50) == 0 && XP >= 256;  // (measured: 2^20, 512 polynomials per launch, -0.5 ms per query; 2^17, 64 per launch, +0.1 ms)
+    if (rcf) {
+        hk::ntt15_inverse_p2(stream, tabs, c.d + (size_t)l * N, t, c.poly_elems(), (size_t)N, XP, last);
+        const CfPlan &cp = cf_plan_rescale(nl);
+        hk::ntt15_colfuse(stream, tabs, t, (size_t)N, tmp, (size_t)l * N, XP, cp.dev, cp.host.data(), 1, false);
+        NttStore stp{};
+        stp.mode = 2;
+        stp.out = out.d;
+        stp.nl = l;
+        stp.in = c.d;
+        stp.in_ls = c.lstride;
+        stp.mul = scale_of(qsel, qi, false);
+        stp.sub = sub ? sub->d : nullptr;
+        stp.sub_ls = sub ? sub->lstride : 0;
+        stp.has_addc = addc ? 1 : 0;
+        stp.npoly = c.npoly;
+        if (addc)
+            for (int j = 0; j < l; j++) stp.addc[j] = double_to_mod(*addc * out.scale, q[j]);
+        hk::ntt15_forward_p2_fused(stream, tabs, tmp, (size_t)l * N, XP, qsel, stp);
+        pool.put(tmp);
+        pool.put(t);
+        c = std::move(out);
+        return;
+    }
+    ntt_inv(c.d + (size_t)l * N, t, c.poly_elems(), (size_t)N, XP, last, scale_ninv(last));
     if (prm.logN == 15 && l <= HY_LC_LIMBS) {
         // spread fused into the NTT's first pass, combine (+ the caller's subtraction / constant) into its second
         NttLoad ld{};

@@ -238,7 +238,8 @@ struct Context : HostParams {
     std::map<std::string, CfPlan> cf_plans;
     const CfPlan &cf_plan_modup(int nl);
     const CfPlan &cf_plan_moddown(int nl, bool premul);          // premul: constants carry P^{-1} (loop A's pre-scaled key shadow)
-    const CfPlan &cf_plan_moddown_rescale(int nl, bool dbl);     // merged ModDown + Rescale from level nl
+    const CfPlan &cf_plan_moddown_rescale(int nl, bool dbl);
+    const CfPlan &cf_plan_rescale(int nl);  // Rescale alone as a column-fused map without conversion sources: u -> every remaining limb     // merged ModDown + Rescale from level nl
     const CfPlan &cf_plan_store(const std::string &key, std::vector<ColFuse> &&maps);
     bool colfuse = true;        // HYDIA_NO_COLFUSE: pass 1' / conversion / pass 1 as three kernels
     bool cf_ok() const { return colfuse && prm.logN == 15 && alpha <= HY_CF_SRC && nP <= HY_CF_SRC; }
@@ -279,6 +280,7 @@ struct Context : HostParams {
     // transform, column-fused ModDown conversion, combine (+ addend, doubling, automorphism) in the last pass.  key: one key for every
     // ciphertext, or d_keys (device array) one per ciphertext.  false: not available here (generic rings, switches) — use ks_apply
     bool ks_fused_ok() const { return prm.logN == 15 && fuse_ip && !relin_separate_intt && cf_ok() && ks_fuse; }
+    bool rescale_cf = true;  // HYDIA_NO_RESCALE_CF: Rescale's spread + first pass as k_ntt15_p1<false, 2> (round 3's form)
     bool ks_fuse = true;  // HYDIA_NO_KS_FUSE: relinearize / rotate / giant steps through modup_digits + ks_apply (round 3's form)
     void ks_fused(const u64 *c1, size_t c1_xs, int X, int nl, const u64 *key, const u64 *const *d_key_cell, const u64 *const *d_keys,
                   const u64 *addend, size_t add_x, size_t add_p, int add_polys, const unsigned *d_ginv, int same_g, bool dbl, u64 *out);
