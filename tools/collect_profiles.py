@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the outputs of tools/gpu_r3_deliver.sh from gpurun_out/ into profiles/<round>/ under a version tag and refresh
+"""Copy the outputs of tools/gpu_r4_deliver.sh (gpu_r3_deliver.sh in round 3) from gpurun_out/ into profiles/<round>/ under a version tag and refresh
 profiles/tensor_traffic.json from the two PMC passes (tagged with the kernel source hash bench.py checks).
 Usage: collect_profiles.py v1 [round directory, default r03]"""
 import csv
@@ -37,7 +37,9 @@ cp("scaling_components_17.json", "scaling_components_2p17_%s.json" % tag)
 cp("smoke.log", "smoke_%s.log" % tag)
 cp("stream_rate.txt", "stream_rate.txt")
 cp("tensor_check.txt", "loop_b_host_check.txt")
-for l in (20, 14, 10):
+cp("sq_counters_tails.txt", "sq_counters_tails_raw_%s.txt" % tag)
+cp("kernel_rooflines_q20.txt", "kernel_rooflines_q20_%s.txt" % tag)
+for l in (20, 17, 14, 10):
     cp("kernel_rooflines_q%d.txt" % l, "kernel_rooflines_q%d_%s.txt" % (l, tag))
     cp("kernel_stats_q%d.csv" % l, "indexscenario_2p%d_queryonly_kernel_stats_%s.csv" % (l, tag))
     cp("ledger_q%d.json" % l, "byte_ledger_q%d_%s.json" % (l, tag))
@@ -69,6 +71,7 @@ out = {
     "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads; MI355X_MICROARCH.md HBM section)",
     "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "resident_bytes_per_launch": bench["roofline"].get("bytes_per_launch"),
     "kernel_sha": kernel_sha(), "commit": head,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (%s %s)" % (ROUND, tag),
 }
