@@ -276,6 +276,12 @@ def main():
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.selftest_launcher and os.environ.get("HYDIA_BENCH_REHEARSE") != "1":
+            import torch  # (counting devices does not initialise the GPU)
+            if torch.cuda.device_count() < args.gpus:
+                sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible on this node (RCCL wants one GPU per rank; HYDIA_BENCH_REHEARSE=1 "
+                                 "runs every rank on GPU 0 over gloo, for control-flow rehearsal only)\n" % (args.gpus, torch.cuda.device_count()))
+                sys.exit(2)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to run a different job than asked\n"

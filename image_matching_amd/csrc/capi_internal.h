@@ -14,7 +14,10 @@
 struct hydia_ctx {
     hydia::Context cx;
     // one reference of the context itself (dropped by hydia_ctx_destroy) + one per live hydia_ct: whoever drops the last one deletes
-    // the context.  Atomic: a binding's finaliser may free a handle on another thread than the one using the context.
+    // the context.  Atomic: a binding's finaliser may free a handle on another thread than the one using the context — which is all
+    // such a free does concurrently: it returns the handle's block to the context's pool, whose free lists are guarded by a mutex
+    // (Pool::mu_), and hipSetDevice only sets the calling thread's current device.  Everything else on a context (queries, key
+    // loading, the database) stays single-threaded: thread-compatible, not thread-safe, like the reference's classes.
     std::atomic<long> refs{1};
     hydia_ctx(const hydia::Params &p, int dev) : cx(p, dev) {}
 };

@@ -51,3 +51,13 @@ def test_external_launcher_still_works():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["ranks_initialised"] == 2 and out["self_launched"] is False
+
+
+def test_more_ranks_than_gpus_is_refused_before_anything_starts():
+    """no GPU in this container: a real (non-rehearsal, non-selftest) multi-GPU run must say so and exit 2 without starting ranks"""
+    import pytest
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the GPUs: nothing to refuse")
+    r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr
