@@ -8,8 +8,8 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_
 echo "pass 2 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_q$L -- python3 $R/tools/prof_query_ledger.py $L 3 > $R/gpurun_out/kt_q$L.log 2>&1 || { tail -5 $R/gpurun_out/kt_q$L.log; exit 1; }
 cd $R
-cp $(ls gpurun_out/kt_q$L/*/*kernel_stats.csv | head -1) gpurun_out/kernel_stats_q$L.csv
-python3 tools/kernel_rooflines.py gpurun_out/kernel_stats_q$L.csv gpurun_out/ledger_q$L.json > gpurun_out/kernel_rooflines_q$L.txt 2>&1 || true
+cp $(ls gpurun_out/kt_q$L/*/*kernel_stats.csv | head -1) gpurun_out/kernel_stats_q${L}_two_lanes.csv
+python3 tools/kernel_rooflines.py gpurun_out/kernel_stats_q${L}_two_lanes.csv gpurun_out/ledger_q$L.json > gpurun_out/kernel_rooflines_q${L}_two_lanes.txt 2>&1 || true
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
