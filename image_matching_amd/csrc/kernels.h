@@ -124,6 +124,7 @@ struct LoopAIp {
                              // nQ, nl for the special-prime limbs whose sums enter the ModDown inverse transform directly)
     int fp;                  // primes below 2^47: products on the FP64 pipe (bit-identical; HYDIA_LOOPA_INT_IP turns it off)
     int premul;              // keys (Q-limb rows) and the converted rows already carry P^{-1}: the combine is a plain subtraction
+    int raw_fp;              // (set at launch) fp && premul: the epilogue takes the FP64 sums unreduced and reduces once (p2_finish5_fp)
 };
 struct NttStore {
     int mode;             // 0 plain (dst in place), 1 ModDown combine, 2 rescale combine, 3 merged ModDown + rescale, 4 inner product, 5 see LoopAIp

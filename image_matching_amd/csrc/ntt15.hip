@@ -314,6 +314,11 @@ DEV void loop_a_ip_fp(const LoopAIp &la, const FpA &ar, const unsigned char *kp,
         a2 += ar.mulmod2(FpA::u2d(v1.x), FpA::u2d(k1.x));
         a3 += ar.mulmod2(FpA::u2d(v1.y), FpA::u2d(k1.y));
     }
+    if (la.raw_fp) {  // the epilogue stays on the FP64 pipe (p2_finish5_fp): the exact small sums as they are, |a| < 3 x 0.55 q
+        o0 = make_ulonglong2(FpA::to_bits(a0), FpA::to_bits(a1));
+        o1 = make_ulonglong2(FpA::to_bits(a2), FpA::to_bits(a3));
+        return;
+    }
     o0 = make_ulonglong2(ar.fin_fwd(a0), ar.fin_fwd(a1));
     o1 = make_ulonglong2(ar.fin_fwd(a2), ar.fin_fwd(a3));
 }
@@ -421,6 +426,8 @@ DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned i
     return r;
 }
 template <int ST>
+DEV void p2_store_perm(const NttStore &st, int xp, int j, unsigned idx, const u64 (&r)[4]);
+template <int ST>
 DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned idx, const u64 v[4], const P2Pre &pre, const P2Prod &po) {
     constexpr size_t N = 32768;
     const u64 q = M.q, mul = st.mul.s[j], muls = st.mul.s_sh[j];
@@ -462,6 +469,12 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
             if (st.has_addc && (xp % st.npoly) == 0) r[k] = addmod(r[k], st.addc[j], q);
         }
     }
+    p2_store_perm<ST>(st, xp, j, idx, r);
+}
+// four finished coefficients idx .. idx+3 of limb j of polynomial xp: stored in place, or through the automorphism (modes 1, 5)
+template <int ST>
+DEV void p2_store_perm(const NttStore &st, int xp, int j, unsigned idx, const u64 (&r)[4]) {
+    constexpr size_t N = 32768;
     u64 *o = st.out + ((size_t)xp * st.nl + j) * N;
     unsigned g = 1u;
     if ((ST == 1 || ST == 5) && st.ginv) g = st.ginv[st.same_g ? 0 : (xp >> 1)];
@@ -487,6 +500,24 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
         *reinterpret_cast<ulonglong2 *>(o + idx + 2) = make_ulonglong2(r[2], r[3]);
     }
 }
+
+// Loop A's combine (mode 5, pre-scaled keys) of a limb below 2^47 on the FP64 pipe (round 4): the inner product's exact small sum minus
+// the transform's UNREDUCED output (+ the addend), ONE reduction — instead of two reductions, a modular subtraction and a modular
+// addition on canonical residues.  Same canonical result.
+DEV void p2_finish5_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigned idx, const double (&v)[4], const P2Pre &pre) {
+    const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
+    const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
+    u64 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double t = FpA::from_bits(iv[k]) - v[k];
+        if (pre.has_ex) t += FpA::u2d(ev[k]);
+        r[k] = ar.fin_fwd(t);
+    }
+    p2_store_perm<5>(st, xp, j, idx, r);
+}
+template <class A>
+DEV void p2_finish5_fp(const NttStore &, const A &, int, int, unsigned, const typename A::T (&)[4], const P2Pre &) {}
 
 // Merged ModDown + Rescale epilogue (mode 3) of a limb below 2^47 on the FP64 pipe (round 4).  The integer form runs two Shoup products
 // with their conditional subtractions per coefficient on the canonical transform output (57 instructions with fin_fwd); but
@@ -745,6 +776,9 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     o1.x = ar.fin_fwd(c2); o1.y = ar.fin_fwd(c3);
                     *reinterpret_cast<ulonglong2 *>(d[p] + e) = o0;
                     *reinterpret_cast<ulonglong2 *>(d[p] + e + 2) = o1;
+                } else if (ST == 5 && std::is_same<A, FpA>::value && stp.la.raw_fp) {
+                    const T cv[4] = {c0, c1, c2, c3};
+                    p2_finish5_fp(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p]);
                 } else if ((ST == 3 || ST == 9 || ST == 10) && std::is_same<A, FpA>::value && !stp.int_epilogue) {
                     const T cv[4] = {c0, c1, c2, c3};
                     p2_finish3_fp<ST == 9 || ST == 10>(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi, po);
@@ -1397,6 +1431,7 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
     }
     NttStore sv = stp;
     sv.int_epilogue = T.int_epilogue;
+    if (ST == 5) sv.la.raw_fp = (stp.la.fp && stp.la.premul && !stp.dbl && !T.int_epilogue && T.twf != nullptr) ? 1 : 0;
     if (pair_polys(X, nsl))
         hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
     else
