@@ -283,7 +283,6 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     if (getenv("HYDIA_NO_PROD_FUSE")) prod_fuse = false;
     if (getenv("HYDIA_NO_KS_FUSE")) ks_fuse = false;
     if (getenv("HYDIA_NO_RESCALE_CF")) rescale_cf = false;
-    if (const char *e = getenv("HYDIA_LANE0_SHARE")) lane0_share = std::max(0.05, std::min(0.95, atof(e)));
     for (int k = 1; k < nlanes; k++) {
         hipStream_t st;
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

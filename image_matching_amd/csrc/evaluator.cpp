@@ -1369,12 +1369,7 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
     std::vector<Ct> res(L);
     Ct out;
     for (int k = 0; k < L; k++) {
-        int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
-        if (L == 2 && lane0_share != 0.5) {  // uneven split: the lanes' identical kernel sequences drift out of step
-            const int cut = std::max(1, std::min(G - 1, (int)std::lround(G * lane0_share)));
-            g0 = k == 0 ? 0 : cut;
-            g1 = k == 0 ? cut : G;
-        }
+        const int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
         set_lane(k);
         if (k > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev[L], 0));
         Ct part = acc.alias(acc.nl);

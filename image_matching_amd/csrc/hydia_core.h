@@ -111,7 +111,6 @@ struct Context : HostParams {
     hipStream_t stream = nullptr;  // the CURRENT lane's stream (lane 0 unless inside a multi-lane section)
     std::vector<hipStream_t> lane_stream;  // lane 0 = the main stream
     int nlanes = 2;                        // comparator lanes (HYDIA_LANES)
-    double lane0_share = 0.5;              // two lanes: fraction of the blocks lane 0 takes (HYDIA_LANE0_SHARE; experiment)
     std::vector<hipEvent_t> lane_ev;
     void set_lane(int k);
     void sync_all();
