@@ -214,6 +214,11 @@ class DistDiagonalSender:
             self.bsgs = self.babies < self.cc.dim
         self.rotation_split = self.rotation_split and self._want_split and not self.bsgs
 
+    def refresh_form(self):
+        """(collective: every rank) re-read the mat-vec form of the resident databases after a re-enrolment / load / re-declaration"""
+        self.rotation_split = self._want_split
+        self._agree_form()
+
     # ---- buffers: int64 tensors that mirror [count][poly][limb][N] residues
     def _buf(self, key, n):
         b = self._bufs.get(key)
@@ -326,8 +331,12 @@ class DistDiagonalSender:
         return cc.import_ct(full.numpy().view(np.uint64).reshape(dim, 2, cc.nQ, cc.N), scale)
 
     def _local(self, fn_name, q):
-        if self._local_form() != self._form:  # re-enrolled, loaded or re-declared since the ranks last agreed
-            self._agree_form()
+        if self._local_form() != self._form:
+            # re-enrolled, loaded or re-declared since the ranks last agreed.  Agreeing again is a collective, and a rank that holds no
+            # block cannot see that the others changed — so it is never started from here: every rank calls refresh_form() (or builds a
+            # new sender) after the databases change
+            raise RuntimeError("DistDiagonalSender: the resident database changed since the ranks agreed on its form (%s -> %s); call "
+                               "refresh_form() on EVERY rank (or construct a new sender) after re-enrolling" % (self._form, self._local_form()))
         if self.rotation_split and self.bsgs:
             raise ValueError("rotation_split (loop A shared out over the ranks) needs hoisted databases; the resident ones are pre-rotated "
                              "for %s babies" % self.babies)
