@@ -1434,6 +1434,12 @@ Ct Context::membership_scenario(const Ct &qc) {
 }
 // EvalAddManyInPlace (sender_diag.cpp:46): the batch summed into its first element's shape, one modular add per block
 Ct Context::add_many(const Ct &s) {
+    if (s.compact() && s.X > 2) {  // one launch: exact 128-bit sums over the batch, one reduction (the same residues as X - 1 modular additions)
+        Ct m(this, 1, s.npoly, s.nl, s.scale);
+        op_bytes("op:add", N, 0, (double)(s.X + 1) * s.npoly * s.nl * N * 8);
+        hk::batch_sum(stream, d_mod, N, s.d, m.d, s.X, s.npoly, s.nl);
+        return m;
+    }
     Ct first = s.alias(s.nl);
     first.X = 1;
     Ct m = clone(first);
