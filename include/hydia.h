@@ -66,7 +66,8 @@ int hydia_params_describe(const hydia_params *p, hydia_info *info, uint64_t *mod
 /* OpenFHEWrapper::computeRequiredDepth, src/openFHE_wrapper.cpp:6-44 */
 size_t hydia_compute_required_depth(size_t approach);
 
-/* replaces GenCryptoContext + Enable(...) (src/main.cpp:169-179) for the sender/receiver on GPU `device` */
+/* replaces GenCryptoContext + Enable(...) (src/main.cpp:169-179) for the sender/receiver on GPU `device`.  No HIP device, or a
+ * device index beyond the ones visible: HYDIA_ERR_DEVICE (a negative index: HYDIA_ERR_ARG) — there is no CPU fallback. */
 int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out);
 /* Same, on a caller-supplied prime chain — the adapter path of SURVEY 8f-3: an OpenFHE context's ciphertext primes
  * (cc->GetElementParams()->GetParams()[j]->GetModulus(), q_0 first) followed by its special primes
@@ -159,7 +160,9 @@ int hydia_db_enroll_shard(hydia_ctx *ctx, double *db, size_t n, const uint8_t se
  * It takes effect at the NEXT enrolment; hydia_db_kind / hydia_db_babies tell what is resident (kind 0 none, 5 hoisted diagonals,
  * 6 pre-rotated diagonals, 4 HERS columns).  Ciphertexts imported one by one (hydia_db_alloc + hydia_db_import_ct: the reference
  * enroller's) are taken as hoisted unless hydia_db_set_babies says otherwise (a database of more than 8 blocks is then re-ordered in
- * HBM for the declared form, through a second buffer of its size — see hydia_db_group). */
+ * HBM for the declared form, through a second buffer of its size — see hydia_db_group).  hydia_db_set_babies takes a DECLARED form:
+ * vector_dim (hoisted) or a power of two >= 2 dividing it — 0, 1 and anything else are HYDIA_ERR_ARG; without a diagonal database
+ * HYDIA_ERR_STATE; when the second buffer does not fit HYDIA_ERR_DEVICE, and the database, its layout and its form are untouched. */
 int hydia_set_matvec(hydia_ctx *ctx, int mode);
 int hydia_get_matvec(const hydia_ctx *ctx);
 int hydia_db_kind(const hydia_ctx *ctx);
@@ -233,6 +236,7 @@ int hydia_ct_mod_reduce(hydia_ctx *ctx, hydia_ct *ct);
 typedef struct hydia_group hydia_group;
 /* block range [lo, hi) of `rank`: the first total_blocks % world ranks take one extra block (host only, no GPU needed) */
 void hydia_shard_blocks(size_t total_blocks, uint32_t world, uint32_t rank, size_t *lo, size_t *hi);
+/* a device index this node does not have: HYDIA_ERR_DEVICE, nothing is created (1 to 16 shards; a negative index: HYDIA_ERR_ARG) */
 int hydia_group_create(const hydia_params *p, const int *devices /* [n_shards] GPU index of each shard */, uint32_t n_shards,
                        hydia_group **out);
 void hydia_group_destroy(hydia_group *g);
