@@ -190,6 +190,9 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HYDIA_BENCH_SELF_LAUNCHED="1")
+        # like torch.distributed.run: one OpenMP thread per rank unless the caller says otherwise — N ranks that each spin up a thread
+        # per host core oversubscribe the CPU (the gloo rehearsal's host staging ran 8x slower: 368 vs 47 ms per step)
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
     rc, out0 = 0, b""
