@@ -409,7 +409,7 @@ DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned i
             r.ex1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
             r.has_ex = true;
         }
-        if ((ST == 3 || ST == 10) && st.sub) {
+        if (ST == 3 && st.sub) {  // (mode 10 loads `sub` where it is used: 16 registers less across the last exchange -> four waves per SIMD)
             const u64 *ps = st.sub + ((size_t)xp * st.sub_ls + j) * N + idx;
             r.sb0 = *reinterpret_cast<const ulonglong2 *>(ps);
             r.sb1 = *reinterpret_cast<const ulonglong2 *>(ps + 2);
@@ -442,14 +442,21 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     }
     if (ST == 3 || ST == 9 || ST == 10) {  // ((in P^{-1} + addend)(x2) - v) q_l^{-1} (- sub)(+ addc): ModDown and Rescale in one epilogue
         const u64 m2 = st.mul2.s[j], m2s = st.mul2.s_sh[j];
-        const u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
+        u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
+        bool has_sb = pre.has_sb;
+        if (ST == 10 && st.sub) {  // loaded here, not across the last exchange (see p2_prefetch)
+            const u64 *ps = st.sub + ((size_t)xp * st.sub_ls + j) * N + idx;
+            const ulonglong2 s0 = *reinterpret_cast<const ulonglong2 *>(ps), s1 = *reinterpret_cast<const ulonglong2 *>(ps + 2);
+            sv[0] = s0.x; sv[1] = s0.y; sv[2] = s1.x; sv[3] = s1.y;
+            has_sb = true;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u64 t = mulmod_shoup(iv[k], mul, muls, q);
             if (has_ex) t = addmod(t, ev[k], q);
             if (st.dbl) t = addmod(t, t, q);
             t = mulmod_shoup(submod(t, v[k], q), m2, m2s, q);
-            if (pre.has_sb) t = st.sub_add ? addmod(t, sv[k], q) : submod(t, sv[k], q);
+            if (has_sb) t = st.sub_add ? addmod(t, sv[k], q) : submod(t, sv[k], q);
             if (st.has_addc && (xp % st.npoly) == 0) t = addmod(t, st.addc[j], q);
             r[k] = t;
         }
@@ -549,13 +556,20 @@ template <>
 DEV Epi3Fp Epi3Fp::make<9, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
 template <>
 DEV Epi3Fp Epi3Fp::make<10, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
-template <bool PROD>
+template <bool PROD, bool LATE_SB>
 DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigned idx, const double (&v)[4], const P2Pre &pre, const Epi3Fp &e,
                        const P2Prod &po) {
     constexpr size_t N = 32768;
     const u64 iv[4] = {pre.in0.x, pre.in0.y, pre.in1.x, pre.in1.y};
     const u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
-    const u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
+    u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
+    bool has_sb = pre.has_sb;
+    if (LATE_SB && st.sub) {
+        const u64 *ps = st.sub + ((size_t)xp * st.sub_ls + j) * N + idx;
+        const ulonglong2 s0 = *reinterpret_cast<const ulonglong2 *>(ps), s1 = *reinterpret_cast<const ulonglong2 *>(ps + 2);
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s1.x; sv[3] = s1.y;
+        has_sb = true;
+    }
     const bool addc = st.has_addc && (xp % st.npoly) == 0;
     u64 r[4];
 #pragma unroll
@@ -563,7 +577,7 @@ DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigne
         double t = ar.mulmod(FpA::u2d(iv[k]), e.k1) - ar.mulmod(v[k], e.k3);
         if (PROD) t += ar.mulmod(po.dp_fp(ar, xp & 1, k), e.k2);
         else if (pre.has_ex) t += ar.mulmod(FpA::u2d(ev[k]), e.k2);
-        if (pre.has_sb) t += st.sub_add ? FpA::u2d(sv[k]) : -FpA::u2d(sv[k]);
+        if (has_sb) t += st.sub_add ? FpA::u2d(sv[k]) : -FpA::u2d(sv[k]);
         if (addc) t += e.addc;
         r[k] = ar.fin_fwd(t);
     }
@@ -571,7 +585,7 @@ DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigne
     *reinterpret_cast<ulonglong2 *>(o3 + idx) = make_ulonglong2(r[0], r[1]);
     *reinterpret_cast<ulonglong2 *>(o3 + idx + 2) = make_ulonglong2(r[2], r[3]);
 }
-template <bool PROD, class A>
+template <bool PROD, bool LATE_SB, class A>
 DEV void p2_finish3_fp(const NttStore &, const A &, int, int, unsigned, const typename A::T (&)[4], const P2Pre &, const Epi3Fp &, const P2Prod &) {}
 
 // The LDS image of a pass-2 workgroup: 8 blocks x 8 rows x 32 coefficients per polynomial.  Padded (rows of 36: phase B's (row, 4k + b)
@@ -781,7 +795,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     p2_finish5_fp(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p]);
                 } else if ((ST == 3 || ST == 9 || ST == 10) && std::is_same<A, FpA>::value && !stp.int_epilogue) {
                     const T cv[4] = {c0, c1, c2, c3};
-                    p2_finish3_fp<ST == 9 || ST == 10>(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi, po);
+                    p2_finish3_fp<ST == 9 || ST == 10, ST == 10>(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi, po);
                 } else {
                     const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
                     p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[SPLIT ? 0 : hh][p], po);
@@ -908,7 +922,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 template <bool INV, int NP, int ST>
 // (loop A's fused inner product asks for three workgroups per CU: unbounded it takes 171 registers — two per CU, 6.24 ms per
 // rotateQuery; at 167 it keeps its twelve loads per call in flight with three, 5.95 ms; capped to 128 it spills, 6.13 ms)
-__global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : 1) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
+__global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : (!INV && ST == 10) ? 4 : 1) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
                                                   size_t dso, LimbSel sel, int slot0, int nsl, NttStore stp) {
     constexpr int N = 32768;
     // (the unpadded image would let five two-polynomial workgroups share a CU instead of four: measured, no gain — 4.05 vs 4.08 ms for
