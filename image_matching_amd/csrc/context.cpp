@@ -281,6 +281,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     lane_stream.push_back(stream);
     if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
     if (getenv("HYDIA_NO_PROD_FUSE")) prod_fuse = false;
+    if (getenv("HYDIA_NO_CSUB_FUSE")) prod_fuse_csub = false;
     if (getenv("HYDIA_NO_KS_FUSE")) ks_fuse = false;
     if (getenv("HYDIA_NO_RESCALE_CF")) rescale_cf = false;
     for (int k = 1; k < nlanes; k++) {

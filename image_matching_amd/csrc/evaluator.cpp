@@ -635,7 +635,8 @@ void Context::relin_rescale(Ct &c, bool dbl, const Ct *sub, const double *addc, 
     c = std::move(out);
 }
 // the merged pipeline: c [X][3][nl][N] -> out_d [X][2][nl - 1][N]
-void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps) {
+void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps,
+                                 const ScaleSel *kap) {
     const int nl = c.nl, l = nl - 1;
     const int nE = nl + nP, nd = (nl + alpha - 1) / alpha, X = c.X, XP = X * 2;
     // relinearise (ModUp nd nE, ModDown 2 (nP + nl)) + rescale (2 nl) transforms per ciphertext: 80 + 24 at nl = 12
@@ -735,6 +736,7 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
     if (ps) {  // d0, d1 of the product are formed in the epilogue
         stp.has_prod = 1;
         stp.prod = *ps;
+        if (ps->c) stp.kap = *kap;
     }
     stp.dbl = dbl ? 1 : 0;
     stp.sub = sub ? sub->d : nullptr;
@@ -879,15 +881,17 @@ bool Context::prod_fusable(int nl) const {
     return prod_fuse && prm.logN == 15 && merge_rescale && fuse_ip && !relin_separate_intt && cf_ok() && l >= 1 && l <= HY_LC_LIMBS && nd >= 2 &&
            nd <= 4 && !tabs.two_ip_launches && !tabs.no_drop_in_ip && (q[l] >> 50) == 0 && relin_key.d != nullptr;
 }
-Ct Context::mult_relin_rescale(const Ct &a, const Ct &b, bool dbl, const Ct *sub, const double *addc, bool sub_is_add) {
+Ct Context::mult_relin_rescale(const Ct &a, const Ct &b, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, const Ct *csub) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
-    const int nl = a.nl, l = nl - 1;
-    if (!prod_fusable(nl) || (sub && (sub->X != a.X || sub->npoly != 2 || sub->nl < l))) {
-        Ct o = mult_norelin(a, b);
+    if (csub && (csub->X != a.X || csub->npoly != 2 || csub->nl != a.nl || !dbl)) throw std::runtime_error("hydia: mult-sub shape mismatch");
+    const int nl = a.nl, l = nl - 1, nd = (nl + alpha - 1) / alpha;
+    // (the tail's subtrahend path exists in the three-and-more-digit kernels only: the steps with a subtrahend run at >= 9 limbs)
+    if (!prod_fusable(nl) || (csub && (!prod_fuse_csub || nd < 3)) || (sub && (sub->X != a.X || sub->npoly != 2 || sub->nl < l))) {
+        Ct o = csub ? mult_norelin_sub(a, b, *csub) : mult_norelin(a, b);
         relin_rescale(o, dbl, sub, addc, sub_is_add);
         return o;
     }
-    op_bytes("op:mult_norelin", N, 0, 7.0 * a.X * a.nl * N * 8);  // the inherent bytes of the product stay what they were
+    op_bytes("op:mult_norelin", N, 0, (csub ? 9.0 : 7.0) * a.X * a.nl * N * 8);  // the inherent bytes of the product stay what they were
     Ct shape;  // shape and scale of the degree-2 ciphertext that is never formed
     shape.ctx = this;
     shape.X = a.X;
@@ -895,9 +899,23 @@ Ct Context::mult_relin_rescale(const Ct &a, const Ct &b, bool dbl, const Ct *sub
     shape.nl = shape.lstride = nl;
     shape.scale = a.scale * b.scale;
     shape.view = true;
-    const ProdSrc ps{a.d, b.d, a.ct_elems(), a.poly_elems(), b.ct_elems(), b.poly_elems()};
+    ProdSrc ps{a.d, b.d, a.ct_elems(), a.poly_elems(), b.ct_elems(), b.poly_elems(), nullptr, 0, 0, 0, 0};
+    ScaleSel kap{};
+    if (csub) {  // d0, d1 -= (K/2 mod q_j) c0, c1 ahead of the doubling relinearisation
+        const u64 K = (u64)std::llround(shape.scale / csub->scale);
+        for (int j = 0; j < nl; j++) {
+            const u64 inv2 = (q[j] + 1) >> 1;
+            kap.s[j] = mulmod_u64(K % q[j], inv2, q[j]);
+            kap.s_sh[j] = shoup_h(kap.s[j], q[j]);
+        }
+        ps.c = csub->d;
+        ps.c_x = csub->ct_elems();
+        ps.c_p = csub->poly_elems();
+        ps.kap_l = kap.s[l];
+        ps.kap_l_sh = kap.s_sh[l];
+    }
     Ct out(this, a.X, 2, l, shape.scale / (double)q[l]);
-    relin_rescale_into(shape, dbl, sub, addc, sub_is_add, out.d, &ps);
+    relin_rescale_into(shape, dbl, sub, addc, sub_is_add, out.d, &ps, &kap);
     return out;
 }
 Ct Context::mult(const Ct &a, const Ct &b) {
@@ -1078,9 +1096,7 @@ Ct cheb_step(Context *cx, const Ct &a, const Ct &b, const Ct *c) {
     const double minus_one = -1.0;
     if (c) {
         Ct cv = c->alias(nl);
-        Ct o = cx->mult_norelin_sub(x, y, cv);
-        cx->relin_rescale(o, true, nullptr, nullptr);
-        return o;
+        return cx->mult_relin_rescale(x, y, true, nullptr, nullptr, false, &cv);
     }
     return cx->mult_relin_rescale(x, y, true, nullptr, &minus_one);
 }

@@ -284,12 +284,16 @@ struct Context : HostParams {
     void ks_fused(const u64 *c1, size_t c1_xs, int X, int nl, const u64 *key, const u64 *const *d_key_cell, const u64 *const *d_keys,
                   const u64 *addend, size_t add_x, size_t add_p, int add_polys, const unsigned *d_ginv, int same_g, bool dbl, u64 *out);
     // ps != nullptr: c carries shape and scale only (X, nl, scale; no data) — the degree-2 ciphertext is the product ps and is never formed
-    void relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps = nullptr);
+    void relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, u64 *out_d, const ProdSrc *ps = nullptr,
+                            const ScaleSel *kap = nullptr);
     // (a b) relinearised (doubled) and rescaled (+- sub)(+ addc): EvalMultNoRelin + relin_rescale, with the tensor fused into its
     // consumers where the merged pipeline runs (prod_fusable)
     bool prod_fuse = true;  // HYDIA_NO_PROD_FUSE: k_tensor materialises every degree-2 ciphertext (round 3's form)
     bool prod_fusable(int nl) const;
-    Ct mult_relin_rescale(const Ct &a, const Ct &b, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false);
+    // csub != nullptr: the Chebyshev step 2ab - K csub (K = round(s_a s_b / s_c): mult_norelin_sub's arithmetic), dbl must be set
+    Ct mult_relin_rescale(const Ct &a, const Ct &b, bool dbl = false, const Ct *sub = nullptr, const double *addc = nullptr, bool sub_is_add = false,
+                          const Ct *csub = nullptr);
+    bool prod_fuse_csub = true;  // HYDIA_NO_CSUB_FUSE: Chebyshev steps with a subtrahend keep k_tensor<true>
     bool merge_rescale = true;      // HYDIA_NO_MERGE_RESCALE: run the two steps separately (A/B)
     Ct clone(const Ct &a);          // compact copy
     void drop_to(Ct &a, int nl);    // O(1): keeps the allocation, lstride unchanged

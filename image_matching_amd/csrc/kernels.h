@@ -80,9 +80,13 @@ struct NttLoad {
 // the merged ModDown + Rescale epilogue (and the dropped limb's tail), d2 = a1 b1 into the load of the relinearisation's inverse
 // transform — the degree-2 ciphertext [x][3][nl][N] never exists in HBM (7 limb-polynomials of traffic per limb and ciphertext and
 // one launch less per product).  a, b: [x][2][..][N] views, limb j of polynomial p of ciphertext x at a + x a_x + p a_p + j N.
+// Optionally minus kap c on d0, d1 (a Chebyshev step 2ab - K c: kap = K/2 mod q_j — per limb in NttStore::kap, at the dropped limb here).
 struct ProdSrc {
     const u64 *a, *b;
     size_t a_x, a_p, b_x, b_p;
+    const u64 *c;  // null: a plain product
+    size_t c_x, c_p;
+    u64 kap_l, kap_l_sh;  // kap at the limb the rescale drops (the tail's addend)
 };
 struct IpArgs {
     const u64 *key;   // [nd][2][nT][N]
@@ -147,6 +151,7 @@ struct NttStore {
     int npoly;
     u64 addc[HY_LC_LIMBS];
     int has_prod;         // mode 3: the addend is d_p of the product `prod` (addend unused); inverse load mode 8: the input is d2 = a1 b1 of `prod`
+    ScaleSel kap;         //         prod.c != null: d_p -= kap[j] c_p
     ProdSrc prod;         //         (mode 8 also writes d2 to `out`, compact [x][nl][N], for the inner product's own-digit rows)
     int int_epilogue;     // mode 3: integer (Shoup) epilogue for every limb (HYDIA_INT_EPILOGUE; default: FP64 for the limbs below 2^47)
     IpArgs ip;            // mode 4

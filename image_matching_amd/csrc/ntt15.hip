@@ -230,6 +230,10 @@ struct P2Prod {
         if (p == 0) return mulmod(a0[k], b0[k], M);
         return reduce128k((u128)a0[k] * b1[k] + (u128)a1[k] * b0[k], M);
     }
+    // the subtrahend's four coefficients of polynomial p (a Chebyshev step's c): loaded where they are used
+    DEV static void load_c(const ProdSrc &ps, int x, int p, int j, unsigned idx, u64 (&cv)[4]) {
+        ld4(ps.c + (size_t)x * ps.c_x + (size_t)p * ps.c_p + (size_t)j * 32768 + idx, cv);
+    }
 };
 // canonical a * b mod q in the arithmetic of the limb
 DEV u64 prod_canon(const FpA &ar, const ModC &, u64 a, u64 b) { return ar.fin_fwd(ar.mulmod2(FpA::u2d(a), FpA::u2d(b))); }
@@ -401,9 +405,9 @@ DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned i
     }
     r.sb0 = r.sb1 = make_ulonglong2(0, 0);
     r.has_sb = false;
-    if (ST == 1 || ST == 3 || ST == 5 || ST == 9 || ST == 10) {
+    if (ST == 1 || ST == 3 || ST == 5 || ST == 9 || ST == 10 || ST == 11) {
         const int x = xp >> 1, p = xp & 1;
-        if (st.addend && p < st.add_polys && ST != 9 && ST != 10) {
+        if (st.addend && p < st.add_polys && ST != 9 && ST != 10 && ST != 11) {
             const u64 *pa = st.addend + (size_t)x * st.add_x + (size_t)p * st.add_p + (size_t)j * N + idx;
             r.ex0 = *reinterpret_cast<const ulonglong2 *>(pa);
             r.ex1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
@@ -435,12 +439,18 @@ DEV void p2_finish(const NttStore &st, const ModC &M, int xp, int j, unsigned id
     u64 ev[4] = {pre.ex0.x, pre.ex0.y, pre.ex1.x, pre.ex1.y};
     u64 r[4];
     bool has_ex = pre.has_ex;
-    if (ST == 9 || ST == 10) {  // the addend is the product's d_p, formed here
+    if (ST == 9 || ST == 10 || ST == 11) {  // the addend is the product's d_p, formed here
 #pragma unroll
         for (int k = 0; k < 4; k++) ev[k] = po.dp_int(M, xp & 1, k);
         has_ex = true;
+        if (ST == 11) {  // d_p -= kap c_p
+            u64 cv[4];
+            P2Prod::load_c(st.prod, xp >> 1, xp & 1, j, idx, cv);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ev[k] = submod(ev[k], mulmod_shoup(cv[k], st.kap.s[j], st.kap.s_sh[j], q), q);
+        }
     }
-    if (ST == 3 || ST == 9 || ST == 10) {  // ((in P^{-1} + addend)(x2) - v) q_l^{-1} (- sub)(+ addc): ModDown and Rescale in one epilogue
+    if (ST == 3 || ST == 9 || ST == 10 || ST == 11) {  // ((in P^{-1} + addend)(x2) - v) q_l^{-1} (- sub)(+ addc): ModDown and Rescale in one epilogue
         const u64 m2 = st.mul2.s[j], m2s = st.mul2.s_sh[j];
         u64 sv[4] = {pre.sb0.x, pre.sb0.y, pre.sb1.x, pre.sb1.y};
         bool has_sb = pre.has_sb;
@@ -533,7 +543,7 @@ DEV void p2_finish5_fp(const NttStore &, const A &, int, int, unsigned, const ty
 // operands as they are — `in`, `ex`, `sb` canonical, v the transform's UNREDUCED output (|v| < 2^50) — and ONE reduction finishes:
 // |sum| < 6q, exact in a double.  35 instructions; the same canonical residue (every step is exact modulo q).
 struct Epi3Fp {
-    double2 k1, k2, k3;
+    double2 k1, k2, k3, kap;
     double addc;
     template <int ST, class A>
     DEV static Epi3Fp make(const NttStore &st, const A &, const ModC &, int) {
@@ -548,6 +558,7 @@ DEV Epi3Fp epi3fp_make(const NttStore &st, const FpA &ar, const ModC &M, int j) 
     e.k2 = ar.tw8(FpA::u2d(two));
     e.k3 = ar.tw8(FpA::u2d(m2));
     e.addc = st.has_addc ? FpA::u2d(st.addc[j]) : 0.0;
+    e.kap = ar.tw8(FpA::u2d(st.has_prod && st.prod.c ? st.kap.s[j] : 0));
     return e;
 }
 template <>
@@ -556,7 +567,9 @@ template <>
 DEV Epi3Fp Epi3Fp::make<9, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
 template <>
 DEV Epi3Fp Epi3Fp::make<10, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
-template <bool PROD, bool LATE_SB>
+template <>
+DEV Epi3Fp Epi3Fp::make<11, FpA>(const NttStore &st, const FpA &ar, const ModC &M, int j) { return epi3fp_make(st, ar, M, j); }
+template <bool PROD, bool LATE_SB, bool HAS_C>
 DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigned idx, const double (&v)[4], const P2Pre &pre, const Epi3Fp &e,
                        const P2Prod &po) {
     constexpr size_t N = 32768;
@@ -571,11 +584,15 @@ DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigne
         has_sb = true;
     }
     const bool addc = st.has_addc && (xp % st.npoly) == 0;
+    u64 cv[4] = {0, 0, 0, 0};
+    constexpr bool has_c = PROD && HAS_C;
+    if (has_c) P2Prod::load_c(st.prod, xp >> 1, xp & 1, j, idx, cv);
     u64 r[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         double t = ar.mulmod(FpA::u2d(iv[k]), e.k1) - ar.mulmod(v[k], e.k3);
-        if (PROD) t += ar.mulmod(po.dp_fp(ar, xp & 1, k), e.k2);
+        if (PROD && has_c) t += ar.mulmod(po.dp_fp(ar, xp & 1, k) - ar.mulmod(FpA::u2d(cv[k]), e.kap), e.k2);
+        else if (PROD) t += ar.mulmod(po.dp_fp(ar, xp & 1, k), e.k2);
         else if (pre.has_ex) t += ar.mulmod(FpA::u2d(ev[k]), e.k2);
         if (has_sb) t += st.sub_add ? FpA::u2d(sv[k]) : -FpA::u2d(sv[k]);
         if (addc) t += e.addc;
@@ -585,7 +602,7 @@ DEV void p2_finish3_fp(const NttStore &st, const FpA &ar, int xp, int j, unsigne
     *reinterpret_cast<ulonglong2 *>(o3 + idx) = make_ulonglong2(r[0], r[1]);
     *reinterpret_cast<ulonglong2 *>(o3 + idx + 2) = make_ulonglong2(r[2], r[3]);
 }
-template <bool PROD, bool LATE_SB, class A>
+template <bool PROD, bool LATE_SB, bool HAS_C, class A>
 DEV void p2_finish3_fp(const NttStore &, const A &, int, int, unsigned, const typename A::T (&)[4], const P2Pre &, const Epi3Fp &, const P2Prod &) {}
 
 // The LDS image of a pass-2 workgroup: 8 blocks x 8 rows x 32 coefficients per polynomial.  Padded (rows of 36: phase B's (row, 4k + b)
@@ -738,7 +755,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         }
         // the merged epilogues' operands are fetched one half at a time (the second half's while the first half is finished): 109 / 120
         // instead of 136 / 150 registers, i.e. 4 instead of 3 waves per SIMD (-0.4 ms per query at 2^14, -0.8 ms at 2^20)
-        constexpr bool SPLIT = ST == 5 || ST == 3 || ST == 9 || ST == 10;  // (9, 10 = 3 with the addend formed from a fused product: no `ex` operand; 9 has no `sub` operand either — 126 registers, four waves per SIMD)
+        constexpr bool SPLIT = ST == 5 || ST == 3 || ST == 9 || ST == 10 || ST == 11;  // (9, 10 = 3 with the addend formed from a fused product: no `ex` operand; 9 has no `sub` operand either — 126 registers, four waves per SIMD)
         const Epi3Fp epi = Epi3Fp::make<ST, A>(stp, ar, M, slot);
         P2Pre pre[2][NP];
         P2Prod po;  // mode 3 with a fused product: a0, a1, b0, b1 of the ciphertext (shared by its two polynomials when NP = 2)
@@ -747,7 +764,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             for (int hh = 0; hh < (SPLIT ? 1 : 2); hh++)
 #pragma unroll
                 for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh), M);
-            if (ST == 9 || ST == 10) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t));
+            if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t));
         }
         __syncthreads();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
@@ -764,7 +781,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             if (SPLIT && hh == 1) {
 #pragma unroll
                 for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024), M);
-                if (ST == 9 || ST == 10) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t + 1024));
+                if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t + 1024));
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) {
@@ -793,9 +810,9 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 } else if (ST == 5 && std::is_same<A, FpA>::value && stp.la.raw_fp) {
                     const T cv[4] = {c0, c1, c2, c3};
                     p2_finish5_fp(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p]);
-                } else if ((ST == 3 || ST == 9 || ST == 10) && std::is_same<A, FpA>::value && !stp.int_epilogue) {
+                } else if ((ST == 3 || ST == 9 || ST == 10 || ST == 11) && std::is_same<A, FpA>::value && !stp.int_epilogue) {
                     const T cv[4] = {c0, c1, c2, c3};
-                    p2_finish3_fp<ST == 9 || ST == 10, ST == 10>(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi, po);
+                    p2_finish3_fp<ST == 9 || ST == 10 || ST == 11, ST == 10, ST == 11>(stp, ar, xp0 + p, slot, (unsigned)(B0 + e), cv, pre[SPLIT ? 0 : hh][p], epi, po);
                 } else {
                     const u64 vv[4] = {ar.fin_fwd(c0), ar.fin_fwd(c1), ar.fin_fwd(c2), ar.fin_fwd(c3)};
                     p2_finish<ST>(stp, M, xp0 + p, slot, (unsigned)(B0 + e), vv, pre[SPLIT ? 0 : hh][p], po);
@@ -827,6 +844,13 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                                 dp.load(stp.ip.drop_prod, xp0, ip_t, (unsigned)ci);
 #pragma unroll
                                 for (int k = 0; k < 4; k++) dv[k] = dp.dp_int(M, pp, k);
+                                if (NP >= 2 && stp.ip.drop_prod.c) {  // (Chebyshev steps with a subtrahend run at >= 9 limbs: three digits, NP >= 2)
+                                    u64 cv[4];
+                                    P2Prod::load_c(stp.ip.drop_prod, xp0, pp, ip_t, (unsigned)ci, cv);
+#pragma unroll
+                                    for (int k = 0; k < 4; k++)
+                                        dv[k] = submod(dv[k], mulmod_shoup(cv[k], stp.ip.drop_prod.kap_l, stp.ip.drop_prod.kap_l_sh, M.q), M.q);
+                                }
                             } else {
                                 const u64 *pa = stp.ip.drop_add + (size_t)xp0 * stp.ip.drop_add_x + (size_t)pp * stp.ip.drop_add_p + (size_t)ip_t * 32768 + ci;
                                 const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(pa), d1 = *reinterpret_cast<const ulonglong2 *>(pa + 2);
@@ -1416,7 +1440,7 @@ static void launch_1p(hipStream_t st, const NttTables &T, const u64 *src, u64 *d
     {
         char name[64];
         snprintf(name, sizeof name, "k_ntt15_1p<%s, %d, %d>", INV ? "true" : "false", LD, ST);
-        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : ST == 9 ? 3.0 : ST == 10 ? 4.0 : 0.0)) * nitems * 262144.0);
+        ledger_add(name, (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : ST == 9 ? 3.0 : ST == 10 ? 4.0 : ST == 11 ? 4.0 : 0.0)) * nitems * 262144.0);
     }
     hipLaunchKernelGGL((k_ntt15_1p<INV, LD, ST>), dim3(nitems), dim3(1024), OP_LDS_ELEMS * sizeof(u64), st, T,
                        INV ? T.itwf : T.twf, INV ? T.itwd : T.twd, T.mod, src, dst, so, dso, sel, slot0, X, nitems, scale, ld, stp);
@@ -1438,7 +1462,7 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
     {   // pass-1 output in, result out, + the epilogue's operands: acc & addend (1), rescale input (2), both + subtrahend (3)
         char name[64];
         snprintf(name, sizeof name, "k_ntt15_p2<false, %d, %d>", pair_polys(X, nsl) ? 2 : 1, ST);
-        double per = (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : ST == 9 ? 3.0 : ST == 10 ? 4.0 : 0.0)) * 262144.0;
+        double per = (2.0 + (ST == 1 ? 1.5 : ST == 2 ? 1.0 : ST == 3 ? 2.0 : ST == 9 ? 3.0 : ST == 10 ? 4.0 : ST == 11 ? 4.0 : 0.0)) * 262144.0;
         if (ST == 5)  // pass-1 output in, result out, addend on every other polynomial, nd key rows (6- or 8-byte residues); digits from L2
             per = 2.5 * 262144.0 + stp.la.nd * 32768.0 * (stp.la.packed_nQ > 0 ? (6.0 * (nsl - 1) + 8.0) / nsl : 8.0);
         ledger_add(name, per * X * nsl);
@@ -1487,6 +1511,7 @@ void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t
     if (stp.mode == 1) launch_p2_fwd<1>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 5) launch_p2_fwd<5>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 2) launch_p2_fwd<2>(st, T, dst, dso, X, sel, 0, sel.n, stp);
+    else if (stp.mode == 3 && stp.has_prod && stp.prod.c && !stp.sub) launch_p2_fwd<11>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 3 && stp.has_prod && stp.sub) launch_p2_fwd<10>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 3 && stp.has_prod) launch_p2_fwd<9>(st, T, dst, dso, X, sel, 0, sel.n, stp);
     else if (stp.mode == 3) launch_p2_fwd<3>(st, T, dst, dso, X, sel, 0, sel.n, stp);

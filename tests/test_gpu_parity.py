@@ -350,6 +350,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         # then that with the integer epilogue, so the product operands go through both epilogue arithmetics
         {"HYDIA_NO_PROD_FUSE": "1"},
         {"HYDIA_INT_EPILOGUE": "1"},
+        {"HYDIA_NO_CSUB_FUSE": "1"},  # ... only the Chebyshev steps with a subtrahend (T3, T5, T7) keep k_tensor<true>
         # ... relinearise-only / rotation key switches (EvalSum, the giant steps of the split mat-vec) through modup_digits + ks_apply
         {"HYDIA_NO_KS_FUSE": "1", "HYDIA_NO_RESCALE_CF": "1"},  # ... and Rescale's spread + first pass as k_ntt15_p1<false, 2>  # ... and the merged epilogue in integers on every limb (default: FP64 below 2^47)
         {"HYDIA_NTT_GENERIC": "1", "HYDIA_NO_COLFUSE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_NO_MERGE_RESCALE": "1"},
@@ -366,7 +367,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
                   "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA", "HYDIA_MODUP_PER_DIGIT",
                   "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP", "HYDIA_NTT_NO_PM", "HYDIA_RELIN_TWO_IP_LAUNCHES",
-                  "HYDIA_NO_COLFUSE", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW", "HYDIA_IP_GROUP", "HYDIA_NTT_GENERIC", "HYDIA_NO_DROP_IN_IP", "HYDIA_INT_EPILOGUE", "HYDIA_NO_PROD_FUSE", "HYDIA_NO_KS_FUSE", "HYDIA_NO_RESCALE_CF"):
+                  "HYDIA_NO_COLFUSE", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW", "HYDIA_IP_GROUP", "HYDIA_NTT_GENERIC", "HYDIA_NO_DROP_IN_IP", "HYDIA_INT_EPILOGUE", "HYDIA_NO_PROD_FUSE", "HYDIA_NO_KS_FUSE", "HYDIA_NO_RESCALE_CF", "HYDIA_NO_CSUB_FUSE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
