@@ -437,7 +437,7 @@ def main():
 
     # everything that describes the database that was TIMED is captured here: the optional weak figure below re-enrols on the same context
     db_resident_bytes = cc.db_stats()[2]
-    db_kind_timed, db_babies_timed, db_group_timed = cc.db_kind(), cc.db_babies(), cc.db_group()
+    db_kind_timed, db_babies_timed, db_group_timed, db_bits_timed = cc.db_kind(), cc.db_babies(), cc.db_group(), cc.db_residue_bits()
     ranks_initialised = dist.get_world_size() if multi else 1
     backend = dist.get_backend() if multi else None
     # inherent bytes of the whole step (outside the timed region): one more query with the byte ledger on; the evaluator records what
@@ -496,7 +496,7 @@ def main():
         wire = resident_bytes / avg_launch_s / 1e9 if launches else 0.0
         traffic = traffic_meta = None
         tpath = os.path.join(ROOT, "profiles", "tensor_traffic.json")
-        knobs = [k for k in ("HYDIA_DB_UNPACKED", "HYDIA_DB_CT_MAJOR", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW") if os.environ.get(k)]
+        knobs = [k for k in ("HYDIA_DB_UNPACKED", "HYDIA_DB_CT_MAJOR", "HYDIA_DB_48BIT", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW") if os.environ.get(k)]
         if os.path.exists(tpath) and not args.random_db and not knobs and world == 1:
             try:
                 tj = json.load(open(tpath))
@@ -533,8 +533,8 @@ def main():
             "vs_baseline": (n_total * args.steps / elapsed) / PUBLISHED_2P20_INDEX_VPS if (world == 1 and n_total == 1 << 20) else None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_name(n_total, world, strong) + ": %d blocks of 16384 vectors on this GPU (%.0f GiB resident in "
-                                   "HBM as 48-bit residues = %.0f GiB of 8-byte ciphertexts, %s), one query per step through indexScenario"
-                                   % (G_local, db_gib, G_local * dim * 2 * nl * N * 8 / 2 ** 30,
+                                   "HBM as %d-bit residues = %.0f GiB of 8-byte ciphertexts, %s), one query per step through indexScenario"
+                                   % (G_local, db_gib, db_bits_timed, G_local * dim * 2 * nl * N * 8 / 2 ** 30,
                                       ("group-sequential layout, groups of %d blocks" % db_group_timed) if db_group_timed else "ciphertext-major layout"),
                        "db_vectors_total": n_total, "db": "random residues" if args.random_db else "real ciphertexts (GPU enroller)",
                        "ring": "N=2^15, 12 Q limbs (60+11x45 bit), 4 P limbs, dnum=3",
@@ -560,8 +560,8 @@ def main():
                          "algorithmic_frac": achieved / HBM_PEAK_GBS, "algorithmic_achieved": achieved, "algorithmic_bytes_per_launch": algo_bytes,
                          "vs_measured_stream_ceiling": wire / 7050.0,
                          "step": step_roofline,
-                         "note": "achieved/frac = bytes RESIDENT in HBM that one loop-B pass has to move (database with 6-byte residues for the "
-                                 "45/46-bit limbs + rotated queries + accumulators at 8 bytes: every byte once) / mean pass duration (HIP events on "
+                         "note": "achieved/frac = bytes RESIDENT in HBM that one loop-B pass has to move (database with 46- or 48-bit residues for the "
+                                 "45/46-bit limbs, see config.workload, + rotated queries + accumulators at 8 bytes: every byte once) / mean pass duration (HIP events on "
                                  "the library's stream) / 8 TB/s: a utilisation, <= 1.  algorithmic_* = the same pass priced by SURVEY 8d at 8 bytes "
                                  "per residue (196608 B per DB vector): it exceeds `achieved` by the 6-byte storage and can pass 1.0 — a byte-saving "
                                  "figure, not a utilisation.  vs_measured_stream_ceiling: against 7.05 TB/s, what this GPU gives a read-once sequential "

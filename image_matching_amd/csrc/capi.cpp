@@ -573,6 +573,11 @@ int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_
     return HYDIA_OK;
 }
 int hydia_db_group(const hydia_ctx *ctx) { return ctx && ctx->cx.d_db ? ctx->cx.db_lay.seq : 0; }
+int hydia_db_residue_bits(const hydia_ctx *ctx) {
+    if (!ctx || !ctx->cx.d_db) return 0;
+    const DbLayout &L = ctx->cx.db_lay;
+    return !L.packed ? 64 : (L.seq && L.bits46) ? 46 : 48;
+}
 
 // ------------------------------------------------------------------ sender
 #define SENDER_CALL(expr)                                 \

@@ -281,6 +281,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     lane_stream.push_back(stream);
     if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
     if (getenv("HYDIA_NO_PROD_FUSE")) prod_fuse = false;
+    if (getenv("HYDIA_DB_48BIT")) db_bits46_ok = false;
     if (getenv("HYDIA_NO_CSUB_FUSE")) prod_fuse_csub = false;
     if (getenv("HYDIA_NO_KS_FUSE")) ks_fuse = false;
     if (getenv("HYDIA_NO_RESCALE_CF")) rescale_cf = false;
@@ -535,22 +536,33 @@ void Context::load_eval_key(int rot, const u64 *host) {
 }
 
 // ------------------------------------------------------------------ resident database
-void Context::db_resize(size_t n_vectors, size_t cts, int form) {
+// the layout loop B wants for `cts` ciphertexts in blocks of `form`: group-sequential for more than 8 blocks, and then with 46-bit
+// residues when every packed limb's modulus is below 2^46 (HYDIA_DB_48BIT keeps 6-byte residues)
+DbLayout Context::db_layout_for(size_t cts, int form) const {
     const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);
-    const size_t bytes = cts * ctm.ct_bytes;
+    if (!(db_seq_ok && db_packed && form >= 2 && cts % (size_t)form == 0)) return ctm;
+    bool b46 = db_bits46_ok;
+    for (int j = 1; j < nQ; j++)
+        if (q[j] >> 46) b46 = false;
+    return hk::db_layout_seq(N, nQ, 1, form, (int)(cts / (size_t)form), tensor_bpp, tensor_nw, b46);
+}
+void Context::db_resize(size_t n_vectors, size_t cts, int form) {
+    const DbLayout want = db_layout_for(cts, form);
+    const size_t bytes = cts * want.ct_bytes + 64;  // (+ the tail a lane's last 16-byte load may touch)
     if (d_db) sync_all();  // the layout may change under a still asynchronous query
-    if (d_db && db_cts != cts) {
+    if (d_db && db_alloc_bytes != bytes) {
         HIP_CHECK(hipFree(d_db));
         d_db = nullptr;
     }
-    if (!d_db && bytes) HIP_CHECK(hipMalloc((void **)&d_db, bytes));
+    if (!d_db && cts) {
+        HIP_CHECK(hipMalloc((void **)&d_db, bytes));
+        db_alloc_bytes = bytes;
+    }
     db_cts = cts;
     db_vectors = n_vectors;
     // loop B walks "blocks" of `form` ciphertexts (the hoisted rotations per query: vector_dim, or the baby count of a pre-rotated
     // database, whose blocks are the (database block, giant step) pairs)
-    db_lay = (db_seq_ok && db_packed && form >= 2 && cts % (size_t)form == 0)
-                 ? hk::db_layout_seq(N, nQ, 1, form, (int)(cts / (size_t)form), tensor_bpp, tensor_nw)
-                 : ctm;
+    db_lay = want;
 }
 // An imported database whose form is declared after the fact (hydia_db_set_babies): same ciphertexts, the order loop B wants for
 // that form.  Needs room for a second copy while it runs — the databases the split is meant for (a few dozen blocks) have it; when
@@ -558,11 +570,8 @@ void Context::db_resize(size_t n_vectors, size_t cts, int form) {
 // the resident database, its layout and its declared form stay what they were.
 void Context::db_relayout(int form) {
     if (!d_db || db_cts == 0) return;
-    const DbLayout ctm = hk::db_layout(N, nQ, db_packed ? 1 : 0);
-    const DbLayout want = (db_seq_ok && db_packed && form >= 2 && db_cts % (size_t)form == 0)
-                              ? hk::db_layout_seq(N, nQ, 1, form, (int)(db_cts / (size_t)form), tensor_bpp, tensor_nw)
-                              : ctm;
-    if (want.seq == db_lay.seq && want.bd == db_lay.bd && want.seq_bpp == db_lay.seq_bpp) return;
+    const DbLayout want = db_layout_for(db_cts, form);
+    if (want.seq == db_lay.seq && want.bd == db_lay.bd && want.seq_bpp == db_lay.seq_bpp && want.bits46 == db_lay.bits46) return;
     sync_all();
     struct Scratch {  // whatever throws below, neither buffer leaks and the resident database is still the old one
         Context *c;
@@ -573,7 +582,7 @@ void Context::db_relayout(int form) {
             if (fresh) (void)hipFree(fresh);
         }
     } s{this};
-    const size_t bytes = db_cts * ctm.ct_bytes;
+    const size_t bytes = db_cts * want.ct_bytes + 64;
     hipError_t e = hipMalloc((void **)&s.fresh, bytes);
     if (e != hipSuccess) {
         pool.trim();  // cached evaluator temporaries may be what stands in the way
@@ -596,6 +605,7 @@ void Context::db_relayout(int form) {
     }
     sync();
     std::swap(d_db, s.fresh);  // the old buffer leaves with the scratch object
+    db_alloc_bytes = bytes;
     db_lay = want;
 }
 namespace {

@@ -198,6 +198,9 @@ struct Context : HostParams {
     void build_giants(int G);
     bool db_packed = true;
     bool db_seq_ok = true;  // many-block hoisted databases take the group-sequential layout (HYDIA_DB_CT_MAJOR turns it off)
+    bool db_bits46_ok = true;  // ... with 46-bit residues for the packed limbs (HYDIA_DB_48BIT turns that off)
+    size_t db_alloc_bytes = 0;
+    DbLayout db_layout_for(size_t cts, int form) const;
     DbLayout db_lay{};      // layout of the resident database (set by db_resize)
     DbLayout db_layout() const { return d_db ? db_lay : hk::db_layout(N, nQ, db_packed ? 1 : 0); }
     // (re)allocates the resident database for `cts` ciphertexts.  form = the hoisted-rotation count its diagonals will be laid out

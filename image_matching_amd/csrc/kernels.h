@@ -253,7 +253,7 @@ void ledger_add(const char *kernel, double bytes);
 size_t ledger_dump(char *out, size_t cap);  // "kernel\tlaunches\tbytes\n" per line; returns the size needed
 
 DbLayout db_layout(int N, int nQ, int packed);                                                     // ciphertext-major
-DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, int nw);          // group-sequential when it applies
+DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, int nw, bool bits46 = false);          // group-sequential when it applies
 // ciphertexts t0 .. t0+X-1 of the database at `db` <-> plain [X][2][nQ][N] residues
 void db_pack(hipStream_t st, int N, int nQ, const u64 *plain, void *db, size_t t0, int X, const DbLayout &L);
 void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, size_t t0, int X, const DbLayout &L);

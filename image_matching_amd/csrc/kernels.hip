@@ -24,6 +24,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 namespace {
 
@@ -586,11 +587,13 @@ DEV DbWalk db_walk(const DbLayout &L, int N, int dim, int j, int tile, int lane,
         w.si = L.ct_bytes;
         w.sp = L.poly_bytes;
     } else {
-        const size_t groups = L.blocks / L.seq;
-        w.base = (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + ((((size_t)tile * groups + grp) * L.bd) * L.seq + u0) * 256 * es + (size_t)lane * 2 * es;
-        w.su = 256 * es;
-        w.si = (size_t)L.seq * 256 * es;
-        w.sp = 128 * es;
+        const size_t groups = L.blocks / L.seq, ub = db_unit_bytes(L, j);
+        // (bits46: the lane's two residues start at bit 92 lane of the unit; it loads 16 bytes from the dword that holds that bit)
+        const size_t in_unit = (L.bits46 && j > 0) ? (size_t)((lane * 92) >> 5) * 4 : (size_t)lane * 2 * es;
+        w.base = (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + ((((size_t)tile * groups + grp) * L.bd) * L.seq + u0) * 2 * ub + in_unit;
+        w.su = 2 * ub;
+        w.si = (size_t)L.seq * 2 * ub;
+        w.sp = ub;
     }
     return w;
 }
@@ -713,7 +716,16 @@ struct Acc24 {
     }
     DEV u128 wide() const { return (u128)ll + ((u128)mid << 24) + ((u128)hh << 48); }
 };
-template <int BPP, int NW>
+// two 46-bit residues at bit `s` (a multiple of 4 below 32) of four dwords (bits46 layout): fetched as one 4-byte-aligned 16-byte load
+struct DbRaw46 {
+    typedef unsigned int u4a __attribute__((ext_vector_type(4), aligned(4)));
+    u4a w;
+    template <bool NT>
+    DEV void load(const unsigned char *p) {
+        w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u4a *>(p)) : *reinterpret_cast<const u4a *>(p);
+    }
+};
+template <int BPP, int NW, bool B46, bool D2 = B46>
 __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor24(const ModC *__restrict__ mod, int N, const u64 *__restrict__ rot,
                                                                const unsigned char *__restrict__ db, u64 *__restrict__ acc,
                                                                int dim, int nl, int Gq, int xcd_map, DbLayout L, int j0, int ng, int nblk) {
@@ -735,9 +747,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor24(const ModC *__res
     for (int u = 0; u < BPP; u++)
 #pragma unroll
         for (int e = 0; e < 2; e++) d0[u][e] = dk[u][e] = d2[u][e] = Acc24{0, 0, 0};
+    typedef typename std::conditional<B46, DbRaw46, DbRaw<true>>::type Raw;
+    const unsigned s46 = (unsigned)(lane * 92) & 31u;  // B46: bit of the lane's first residue inside its first dword
     struct Operands {
         ulonglong2 a0, a1;
-        DbRaw<true> b0[BPP], b1[BPP];
+        Raw b0[BPP], b1[BPP];
     };
     auto fetch = [&](Operands &o, int i) {
         o.a0 = *reinterpret_cast<const ulonglong2 *>(ra + (size_t)i * cs);
@@ -771,10 +785,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor24(const ModC *__res
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const auto w = p == 0 ? o.b0[u].w : o.b1[u].w;
-                bl[p][0] = hide24(w.x & 0xFFFFFFu);
-                bh[p][0] = hide24(__builtin_amdgcn_alignbit(w.y, w.x, 24) & 0xFFFFFFu);
-                bl[p][1] = hide24(__builtin_amdgcn_alignbit(w.z, w.y, 16) & 0xFFFFFFu);
-                bh[p][1] = hide24(w.z >> 8);
+                if constexpr (B46) {  // T = (w3:w2:w1:w0) >> s: residue 0 = T[0, 46), residue 1 = T[46, 92); halves of 24 and 22 bits
+                    const unsigned t0 = __builtin_amdgcn_alignbit(w[1], w[0], s46), t1 = __builtin_amdgcn_alignbit(w[2], w[1], s46),
+                                   t2 = __builtin_amdgcn_alignbit(w[3], w[2], s46);
+                    bl[p][0] = hide24(t0 & 0xFFFFFFu);
+                    bh[p][0] = hide24(__builtin_amdgcn_alignbit(t1, t0, 24) & 0x3FFFFFu);
+                    bl[p][1] = hide24(__builtin_amdgcn_alignbit(t2, t1, 14) & 0xFFFFFFu);
+                    bh[p][1] = hide24((t2 >> 6) & 0x3FFFFFu);
+                } else {
+                    bl[p][0] = hide24(w[0] & 0xFFFFFFu);
+                    bh[p][0] = hide24(__builtin_amdgcn_alignbit(w[1], w[0], 24) & 0xFFFFFFu);
+                    bl[p][1] = hide24(__builtin_amdgcn_alignbit(w[2], w[1], 16) & 0xFFFFFFu);
+                    bh[p][1] = hide24(w[2] >> 8);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 2; e++) {
@@ -784,15 +807,38 @@ __global__ __launch_bounds__(64 * NW, 2) void k_hydia_tensor24(const ModC *__res
             }
         }
     };
-    Operands cur, nxt;
-    fetch(cur, 0);
-    for (int i = 0; i < dim; i += 2) {  // dim is a power of two >= 2; no branch inside (see k_hydia_tensor)
-        fetch(nxt, i + 1);
-        accumulate(cur);
-        if (NW > 1) __builtin_amdgcn_s_barrier();
-        fetch(cur, i + 2 < dim ? i + 2 : i + 1);
-        accumulate(nxt);
-        if (NW > 1) __builtin_amdgcn_s_barrier();
+    if constexpr (D2) {
+        // 46-bit units: 4 % fewer bytes per diagonal, and with one diagonal in flight per wave the launch did not get shorter — it is
+        // bound by what a CU keeps in flight (3 workgroups x one diagonal = 35 KB; 1.4 us of latency), not by HBM.  So the database
+        // operands run TWO diagonals ahead here (three rotating sets), the rotated-query lines (L2) one ahead as before.
+        Operands A, B, C;
+        fetch(A, 0);
+        fetch(B, 1);
+        int i = 0;
+        for (; i + 2 < dim; i += 3) {  // branch-free inside: clamped re-fetches of the last diagonal are never accumulated
+            fetch(C, i + 2);
+            accumulate(A);
+            if (NW > 1) __builtin_amdgcn_s_barrier();
+            fetch(A, i + 3 < dim ? i + 3 : dim - 1);
+            accumulate(B);
+            if (NW > 1) __builtin_amdgcn_s_barrier();
+            fetch(B, i + 4 < dim ? i + 4 : dim - 1);
+            accumulate(C);
+            if (NW > 1) __builtin_amdgcn_s_barrier();
+        }
+        if (i < dim) accumulate(A);      // the one or two diagonals the groups of three leave over (workgroup-uniform)
+        if (i + 1 < dim) accumulate(B);
+    } else {
+        Operands cur, nxt;
+        fetch(cur, 0);
+        for (int i = 0; i < dim; i += 2) {  // dim is a power of two >= 2; no branch inside (see k_hydia_tensor)
+            fetch(nxt, i + 1);
+            accumulate(cur);
+            if (NW > 1) __builtin_amdgcn_s_barrier();
+            fetch(cur, i + 2 < dim ? i + 2 : i + 1);
+            accumulate(nxt);
+            if (NW > 1) __builtin_amdgcn_s_barrier();
+        }
     }
 #pragma unroll
     for (int u = 0; u < BPP; u++) {
@@ -892,6 +938,43 @@ __global__ __launch_bounds__(256) void k_db_repack(int N, int nQ, u64 *__restric
         }
     } else {
         *reinterpret_cast<ulonglong2 *>(pl) = pk ? db_load2<true, false>(d) : db_load2<false, false>(d);
+    }
+}
+
+// the 46-bit limbs of a bits46 layout: a thread moves SIXTEEN residues = 23 dwords (the granule that starts on a dword).
+// grid (N/4096, nQ - 1, X*2): limb j = blockIdx.y + 1
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_db_repack46(int N, int nQ, u64 *__restrict__ plain, unsigned char *__restrict__ db, DbLayout L, size_t t0) {
+    const int j = blockIdx.y + 1, xp = blockIdx.z, x = xp >> 1, p = xp & 1;
+    const size_t c = (size_t)(blockIdx.x * 256 + threadIdx.x) * 16;
+    if (c >= (size_t)N) return;
+    u64 *pl = plain + ((size_t)xp * nQ + j) * N + c;
+    unsigned *d = reinterpret_cast<unsigned *>(db + db_offset(L, N, t0 + x, p, j, c));
+    unsigned w[24];
+    if (PACK) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) w[k] = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u64 v = pl[r] & ((1ull << 46) - 1);
+            const int bit = 46 * r, di = bit >> 5, sh = bit & 31;
+            w[di] |= (unsigned)(v << sh);
+            w[di + 1] |= (unsigned)(sh ? v >> (32 - sh) : v >> 32);
+            if (sh > 18) w[di + 2] |= (unsigned)(v >> (64 - sh));  // 46 + sh > 64: the field reaches a third dword
+        }
+#pragma unroll
+        for (int k = 0; k < 23; k++) d[k] = w[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 23; k++) w[k] = d[k];
+        w[23] = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int bit = 46 * r, di = bit >> 5, sh = bit & 31;
+            u64 v = ((u64)w[di] >> sh) | ((u64)w[di + 1] << (32 - sh));
+            if (sh > 18) v |= (u64)w[di + 2] << (64 - sh);
+            pl[r] = v & ((1ull << 46) - 1);
+        }
     }
 }
 
@@ -1102,7 +1185,7 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
     const dim3 blk(64 * NW);
     const bool h24 = L.packed && L.seq && dim <= 4096;  // the 24-bit-halves kernel: its partial sums hold 4096 diagonals
     {   // resident database (6- or 8-byte residues) + rotated queries once + accumulators, split limb 0 / other limbs like the launches
-        const double per_lp6 = (double)N * 6.0, per_lp8 = LP_BYTES(N);
+        const double per_lp6 = (double)N * (L.bits46 ? 5.75 : 6.0), per_lp8 = LP_BYTES(N);
         const double rot_acc = (double)dim * 2 * per_lp8 + (double)G * 3 * per_lp8;
         char n0[64], n1[64];
         snprintf(n0, sizeof n0, "k_hydia_tensor<%d, %d, true, false>", BPP, NW);
@@ -1124,8 +1207,12 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, false>), dim3((N / 128) * Gq, 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl,
                                Gq, xm, L, 0, ng, nblk);
         if (nl > 1 && h24)
-            hipLaunchKernelGGL((k_hydia_tensor24<BPP, NW>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl, Gq, xm, L,
-                               1, ng, nblk);
+            if (L.bits46)
+                hipLaunchKernelGGL((k_hydia_tensor24<BPP, NW, true>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl, Gq, xm, L,
+                                   1, ng, nblk);
+            else
+                hipLaunchKernelGGL((k_hydia_tensor24<BPP, NW, false>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc, dim, nl, Gq, xm, L,
+                                   1, ng, nblk);
         else if (nl > 1)
             hipLaunchKernelGGL((k_hydia_tensor<BPP, NW, true, true>), dim3((N / 128) * Gq, nl - 1), blk, 0, st, mod, N, rot, dbb, acc,
                                dim, nl, Gq, xm, L, 1, ng, nblk);
@@ -1152,6 +1239,7 @@ void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *
     int B, W;
     tensor_split(G, bpp, nw, &B, &W);
     if (L.seq) {  // the layout fixes the workgroup's share: a group of the database is what one workgroup walks
+        if (L.bits46 && !(L.packed && dim <= 4096)) throw std::logic_error("hydia: 46-bit database outside the 24-bit-halves loop B");
         if (G != L.blocks || dim != L.bd || L.seq % L.seq_bpp || G % L.seq || G <= 8)
             throw std::logic_error("hydia: loop B launched against a group-sequential database with another shape");
         B = L.seq_bpp;
@@ -1174,7 +1262,7 @@ DbLayout db_layout(int N, int nQ, int packed) {
 }
 // group-sequential for `blocks` blocks of bd ciphertexts: only where loop B is a stream worth shaping (more than 8 blocks, whole
 // 128-residue tiles) — otherwise the ciphertext-major layout comes back
-DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, int nw) {
+DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, int nw, bool bits46) {
     DbLayout L = db_layout(N, nQ, packed);
     if (blocks <= 8 || N % 128) return L;
     int B, W;
@@ -1183,14 +1271,24 @@ DbLayout db_layout_seq(int N, int nQ, int packed, int bd, int blocks, int bpp, i
     L.seq_bpp = B;
     L.bd = bd;
     L.blocks = blocks;
+    if (bits46 && packed && bd <= 4096) {  // 46-bit residues for the packed limbs (the caller vouches for the moduli)
+        L.bits46 = 1;
+        L.poly_bytes = (unsigned long long)N * 8 + (unsigned long long)(nQ - 1) * (N / 128) * 736;
+        L.ct_bytes = 2 * L.poly_bytes;
+    }
     return L;
 }
 void db_pack(hipStream_t st, int N, int nQ, const u64 *plain, void *db, size_t t0, int X, const DbLayout &L) {
-    hipLaunchKernelGGL(k_db_repack<true>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, const_cast<u64 *>(plain),
+    const bool b46 = L.bits46 && L.seq && L.packed && nQ > 1;  // limb 0 through the pair kernel, the 46-bit limbs through the granule kernel
+    hipLaunchKernelGGL(k_db_repack<true>, dim3(N / 512, b46 ? 1 : nQ, X * 2), dim3(256), 0, st, N, nQ, const_cast<u64 *>(plain),
                        (unsigned char *)db, L, t0);
+    if (b46)
+        hipLaunchKernelGGL(k_db_repack46<true>, dim3((N / 16 + 255) / 256, nQ - 1, X * 2), dim3(256), 0, st, N, nQ, const_cast<u64 *>(plain), (unsigned char *)db, L, t0);
 }
 void db_unpack(hipStream_t st, int N, int nQ, u64 *plain, const void *db, size_t t0, int X, const DbLayout &L) {
-    hipLaunchKernelGGL(k_db_repack<false>, dim3(N / 512, nQ, X * 2), dim3(256), 0, st, N, nQ, plain, (unsigned char *)db, L, t0);
+    const bool b46 = L.bits46 && L.seq && L.packed && nQ > 1;
+    hipLaunchKernelGGL(k_db_repack<false>, dim3(N / 512, b46 ? 1 : nQ, X * 2), dim3(256), 0, st, N, nQ, plain, (unsigned char *)db, L, t0);
+    if (b46) hipLaunchKernelGGL(k_db_repack46<false>, dim3((N / 16 + 255) / 256, nQ - 1, X * 2), dim3(256), 0, st, N, nQ, plain, (unsigned char *)db, L, t0);
 }
 const char *hydia_tensor_kernel_name() { return "k_hydia_tensor"; }
 void fill_uniform_hash(hipStream_t st, const ModC *mod, int N, u64 *dst, size_t n_limbpolys, int nl,

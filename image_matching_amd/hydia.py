@@ -149,6 +149,7 @@ def load_library():
         "hydia_kernel_time": (i32, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(u64)]),
         "hydia_kernel_time_reset": (i32, [vp]),
         "hydia_byte_ledger": (i32, [i32, C.c_char_p, sz, C.POINTER(sz)]),
+        "hydia_db_residue_bits": (i32, [vp]),
         "hydia_bench_ntt": (i32, [vp, u32, u32, u32, i32, u32, C.POINTER(dbl)]),
     }
     for name, (res, args) in sig.items():
@@ -502,6 +503,10 @@ class Context:
     def auto_babies(self, blocks):
         """what an enrolment of `blocks` 16384-vector blocks on this context would pick (its policy applied)"""
         return int(self.L.hydia_auto_babies(self.h, blocks))
+
+    def db_residue_bits(self):
+        """bits per stored residue of the 45/46-bit limbs of the resident database (46, 48 or 64; 0 = none)"""
+        return int(self.L.hydia_db_residue_bits(self.h))
 
     def db_group(self):
         """0: the resident database is ciphertext-major; g > 0: group-sequential with groups of g blocks (hydia_db_group)"""

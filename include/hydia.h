@@ -193,6 +193,10 @@ int hydia_db_stats(const hydia_ctx *ctx, size_t *n_vectors, size_t *n_cts, size_
  * (hydia_db_import_ct / hydia_db_export_ct address ciphertexts, hydia_db_save writes the ciphertext-major file format whatever the
  * resident layout); HYDIA_DB_CT_MAJOR=1 at context creation keeps every database ciphertext-major. */
 int hydia_db_group(const hydia_ctx *ctx);
+/* bits per stored residue of the 45/46-bit limbs of the resident database: 46 (group-sequential layout: 128 residues in a 736-byte
+ * unit; round 4), 48 (6-byte residues: ciphertext-major layout, HYDIA_DB_48BIT, files) or 64 (HYDIA_DB_UNPACKED); 0 without a database.
+ * Limb 0 (60 bit) always takes 8 bytes.  hydia_db_stats reports the bytes this makes resident. */
+int hydia_db_residue_bits(const hydia_ctx *ctx);
 
 /* ---- sender: DiagonalSender (src/sender/sender_diag.cpp) ---- */
 /* loop A alone (:20-26): the vector_dim rotated queries, rot[0] = q */

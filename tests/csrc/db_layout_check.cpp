@@ -8,10 +8,11 @@
 
 #include "db_layout.h"
 
-static DbLayout make(int N, int nQ, int packed, int bd, int blocks, int gs, int bpp) {
+static DbLayout make(int N, int nQ, int packed, int bd, int blocks, int gs, int bpp, int bits46) {
     DbLayout L{};
     L.packed = packed;
-    L.poly_bytes = packed ? (unsigned long long)N * 8 + (unsigned long long)(nQ - 1) * N * 6 : (unsigned long long)nQ * N * 8;
+    L.bits46 = (bits46 && gs && packed) ? 1 : 0;
+    L.poly_bytes = packed ? (unsigned long long)N * 8 + (unsigned long long)(nQ - 1) * (L.bits46 ? (N / 128) * 736 : N * 6) : (unsigned long long)nQ * N * 8;
     L.ct_bytes = 2 * L.poly_bytes;
     L.seq = gs;
     L.seq_bpp = bpp;
@@ -20,17 +21,18 @@ static DbLayout make(int N, int nQ, int packed, int bd, int blocks, int gs, int 
     return L;
 }
 
-static int check(int N, int nQ, int packed, int bd, int blocks, int gs) {
-    const DbLayout L = make(N, nQ, packed, bd, blocks, gs, 1);
+static int check(int N, int nQ, int packed, int bd, int blocks, int gs, int bits46 = 0) {
+    const DbLayout L = make(N, nQ, packed, bd, blocks, gs, 1, bits46);
     const size_t cts = (size_t)bd * blocks, total = cts * L.ct_bytes;
     std::vector<unsigned char> used(total, 0);
     for (size_t t = 0; t < cts; t++)
         for (int p = 0; p < 2; p++)
             for (int j = 0; j < nQ; j++)
-                for (size_t c = 0; c < (size_t)N; c += 2) {
-                    const size_t es = (packed && j > 0) ? 6 : 8, o = db_offset(L, N, t, p, j, c);
+                for (size_t c = 0; c < (size_t)N; c += (L.bits46 && j > 0) ? 16 : 2) {
+                    // granule: a pair of 6- / 8-byte residues, or sixteen 46-bit residues = 92 bytes
+                    const size_t es = (L.bits46 && j > 0) ? 46 : (packed && j > 0) ? 6 : 8, o = db_offset(L, N, t, p, j, c);
                     if (o + 2 * es > total) return printf("out of range: t %zu p %d j %d c %zu\n", t, p, j, c), 1;
-                    if (db_offset(L, N, t, p, j, c) + es != o + es) return 1;
+                    if (o % 4) return printf("granule not on a dword: t %zu p %d j %d c %zu\n", t, p, j, c), 1;
                     for (size_t k = 0; k < 2 * es; k++) {
                         if (used[o + k]) return printf("overlap at byte %zu (t %zu p %d j %d c %zu)\n", o + k, t, p, j, c), 1;
                         used[o + k] = 1;
@@ -42,14 +44,13 @@ static int check(int N, int nQ, int packed, int bd, int blocks, int gs) {
         for (int j = 0; j < nQ; j++)
             for (int tile = 0; tile < N / 128; tile++)
                 for (int grp = 0; grp < blocks / gs; grp++) {
-                    const size_t es = (packed && j > 0) ? 6 : 8;
                     size_t expect = db_offset(L, N, (size_t)grp * gs * bd, 0, j, (size_t)tile * 128);
                     for (int i = 0; i < bd; i++)
                         for (int u = 0; u < gs; u++)
                             for (int p = 0; p < 2; p++) {
                                 const size_t o = db_offset(L, N, ((size_t)grp * gs + u) * bd + i, p, j, (size_t)tile * 128);
                                 if (o != expect) return printf("run broken: j %d tile %d grp %d i %d u %d p %d\n", j, tile, grp, i, u, p), 1;
-                                expect += 128 * es;
+                                expect += db_unit_bytes(L, j);
                             }
                 }
     }
@@ -64,6 +65,9 @@ int main() {
     bad |= check(256, 4, 1, 8, 16, 8);
     bad |= check(512, 2, 1, 2, 9, 1);   // degenerate groups of one block
     bad |= check(256, 3, 1, 4, 20, 2);
+    bad |= check(256, 3, 1, 4, 12, 4, 1);  // group-sequential with 46-bit residues in 736-byte units
+    bad |= check(512, 4, 1, 8, 16, 8, 1);
+    bad |= check(256, 2, 1, 2, 10, 2, 1);
     if (!bad) printf("db layout ok\n");
     return bad;
 }

@@ -4,7 +4,8 @@
 // miscompiled the 24-bit-halves kernel (k_hydia_tensor24) — it dropped the operand masks and fused unmasked registers back into
 // v_mad_u64_u32 — and only a host recomputation shows that; a compiler bump could bring it back at dim 512.  What it replaces:
 // 512 x EvalMultNoRelin + 511 x EvalAddInPlace per block, /root/reference/src/sender/sender_diag.cpp:70-77,:93.
-// Usage: loop_b_check <blocks> <dim> <logN> <0 = ciphertext-major | 1 = the layout the context picks (group-sequential above 8 blocks)>
+// Usage: loop_b_check <blocks> <dim> <logN> <0 = ciphertext-major | 1 = the layout the context picks (group-sequential above 8 blocks,
+//        46-bit residues) | 2 = group-sequential with 48-bit residues>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -25,13 +26,15 @@ static inline u64 hash_residue(u64 seed, size_t idx, u64 q) {  // k_fill_uniform
 
 int main(int argc, char **argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 2, dim = argc > 2 ? atoi(argv[2]) : 8, logN = argc > 3 ? atoi(argv[3]) : 11;
-    const bool pick = argc > 4 ? atoi(argv[4]) != 0 : true;
+    const int mode = argc > 4 ? atoi(argv[4]) : 1;
+    const bool pick = mode != 0;
     Params p;
     p.logN = logN;
     p.dim = dim;
     Context cx(p, 0);
     const int N = cx.N, nl = cx.nQ;
     if (!pick) cx.db_seq_ok = false;
+    if (mode == 2) cx.db_bits46_ok = false;
     const size_t cts = (size_t)G * dim, e = (size_t)2 * nl * N;
     if ((size_t)dim * 2 * nl > 32768 - 32768 % (size_t)nl) {
         printf("block too large for one fill launch\n");
@@ -40,8 +43,8 @@ int main(int argc, char **argv) {
     cx.db_resize((size_t)G * cx.slots, cts, dim);
     cx.db_kind = 5;
     cx.db_babies = dim;
-    printf("N = 2^%d, dim %d, %d blocks: %s layout (groups of %d blocks), %.2f GiB resident\n", logN, dim, G,
-           cx.db_lay.seq ? "group-sequential" : "ciphertext-major", cx.db_lay.seq, (double)cts * cx.db_lay.ct_bytes / (1 << 30));
+    printf("N = 2^%d, dim %d, %d blocks: %s layout (groups of %d blocks, %d-bit packed residues), %.2f GiB resident\n", logN, dim, G,
+           cx.db_lay.seq ? "group-sequential" : "ciphertext-major", cx.db_lay.seq, cx.db_lay.bits46 ? 46 : 48, (double)cts * cx.db_lay.ct_bytes / (1 << 30));
     const u64 seed_rot = 11, seed_db = 1200;
     Ct rot(&cx, dim, 2, nl, cx.delta);
     hk::fill_uniform_hash(cx.stream, cx.d_mod, N, rot.d, (size_t)dim * 2 * nl, nl, seed_rot);

@@ -173,11 +173,11 @@ def test_auto_tiers_and_headline_kernel_bit_exact_full_ring(im, full, blocks, ma
     cc.db_alloc(1)  # give the HBM back to the tests that follow
 
 
-@pytest.mark.parametrize("blocks,pick", [(16, 1), (24, 1), (8, 1), (16, 0)])
+@pytest.mark.parametrize("blocks,pick", [(16, 1), (24, 1), (8, 1), (16, 0), (16, 2)])
 def test_loop_b_against_host_recomputation_full_ring(blocks, pick):
     """The headline kernel directly: loop B as a query runs it (Context::similarity_accumulate_rot) at N = 2^15, dim = 512 — the
-    24-bit-halves kernel on the group-sequential layout (16 and 24 blocks), the 128-bit kernel on ciphertext-major databases (8
-    blocks; 16 with the layout forced) — against unsigned __int128 on the host: 0 mismatches over every (block, limb, coefficient).
+    24-bit-halves kernel on the group-sequential layout (16 and 24 blocks with 46-bit residues, 16 with 48-bit ones), the 128-bit
+    kernel on ciphertext-major databases (8 blocks; 16 with the layout forced) — against unsigned __int128 on the host: 0 mismatches over every (block, limb, coefficient).
     tests/csrc/loop_b_check.cpp, built by __graft_entry__.build(); this is the check that found ROCm 7.2's miscompile of that kernel."""
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "loop_b_check")
@@ -185,6 +185,7 @@ def test_loop_b_against_host_recomputation_full_ring(blocks, pick):
     r = subprocess.run([exe, str(blocks), "512", "15", str(pick)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ("group-sequential" if (pick and blocks > 8) else "ciphertext-major") in r.stdout
+    assert ("46-bit" if (pick == 1 and blocks > 8) else "48-bit") in r.stdout
     assert " 0 mismatches of %d " % (blocks * 12 * 32768) in r.stdout
 
 

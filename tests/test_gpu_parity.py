@@ -385,7 +385,7 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("blocks,group,env", [(10, 2, {}), (16, 8, {}), (12, 4, {"HYDIA_TENSOR_BPP": "1"})])
+@pytest.mark.parametrize("blocks,group,env", [(10, 2, {}), (16, 8, {}), (12, 4, {"HYDIA_TENSOR_BPP": "1"}), (16, 8, {"HYDIA_DB_48BIT": "1"})])
 def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group, env, tmp_path, monkeypatch):
     """A hoisted database of more than 8 blocks lies group-sequentially in HBM (loop B's 24-bit-halves kernel reads
     it).  Same ciphertexts in, same ciphertexts out as the oracle — through the GPU enroller and through ciphertext-by-ciphertext
@@ -413,6 +413,7 @@ def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group
     try:
         im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=41)
         assert cc.db_group() == group and cc.db_kind() == 5
+        assert cc.db_residue_bits() == (48 if "HYDIA_DB_48BIT" in env else 46)  # round 4: 46-bit residues in 736-byte units
         for t in (0, 1, P.dim - 1, P.dim, len(dbc) // 2 + 3, len(dbc) - 1):
             assert np.array_equal(cc.db_export_ct(t), dbc[t].data()), t
         sender = im.DiagonalSender(cc, n)
@@ -458,12 +459,13 @@ def test_group_sequential_database_bit_exact_small_ring(im, small, blocks, group
 
 def test_db_relayout_without_room_fails_cleanly_and_bad_declarations_are_refused(im):
     """hydia_db_set_babies on a database that is laid out for another form re-orders it through a second buffer.  A 2^20-vector
-    database (148 GiB) cannot have one on a 288 GB GPU: the call must fail with HYDIA_ERR_DEVICE before anything is touched — same
+    database (142 GiB, beside 12 GiB of keys) cannot have one on a 288 GiB GPU: the call must fail with HYDIA_ERR_DEVICE before anything is touched — same
     ciphertexts, same declared form, same layout, and the context still answers queries.  Declarations that are not a form
     (0, 1, 3, negative, > vector_dim) are argument errors (round-3 advice: 0 used to mark a hoisted database as pre-rotated)."""
     cc = im.Context()
     try:
         cc.set_matvec("hoisted")
+        cc.fill_eval_keys_random(1)  # 12 GiB of keys beside the database: two copies of it cannot both fit any more
         cc.db_fill_random(1 << 20, 5)
         assert cc.db_kind() == 5 and cc.db_babies() == 512 and cc.db_group() == 8 and cc.db_stats()[2] > 140 << 30
         before = {t: cc.db_export_ct(t) for t in (0, 777, 32767)}
@@ -486,7 +488,6 @@ def test_db_relayout_without_room_fails_cleanly_and_bad_declarations_are_refused
         cc.db_set_babies(512)
         assert cc.db_kind() == 5 and np.array_equal(cc.db_export_ct(600), want)
         # rotation ranges are validated on the unsigned values before anything is allocated (first + count must not wrap)
-        cc.fill_eval_keys_random(1)
         rng = np.random.default_rng(0)
         q = np.stack([rng.integers(0, int(m), size=(2, cc.N), dtype=np.uint64) for m in cc.moduli[:cc.nQ]], axis=1)
         gq = cc.import_ct(q, cc.delta)
