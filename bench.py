@@ -4,7 +4,7 @@
 A "step" is ONE query through DiagonalSender::indexScenario (/root/reference/src/sender/sender_diag.cpp:52-63: 511 hoisted
 rotations, per block 512 tensor products + 1 relinearise + 1 rescale, degree-59 Chebyshev o f4 comparator) over the
 encrypted database resident in HBM.
-  N = 1   the 2^20-vector database (64 blocks, 148 GiB resident) on one GPU — the configuration BASELINE.json quotes its target on.
+  N = 1   the 2^20-vector database (64 blocks, 142.5 GiB resident) on one GPU — the configuration BASELINE.json quotes its target on.
   N > 1   STRONG scaling by default: the SAME 2^20-vector database sharded by 16384-vector row-blocks over the N ranks
           (BASELINE config 5 at N = 8: 8 blocks per GPU; `--total-log2n 17` at N = 4 is config 4), through
           image_matching_amd.sharding.DistDiagonalSender — the class the tests pin bit-exactly against one context: rank 0's query
@@ -563,7 +563,7 @@ def main():
                          "note": "achieved/frac = bytes RESIDENT in HBM that one loop-B pass has to move (database with 46- or 48-bit residues for the "
                                  "45/46-bit limbs, see config.workload, + rotated queries + accumulators at 8 bytes: every byte once) / mean pass duration (HIP events on "
                                  "the library's stream) / 8 TB/s: a utilisation, <= 1.  algorithmic_* = the same pass priced by SURVEY 8d at 8 bytes "
-                                 "per residue (196608 B per DB vector): it exceeds `achieved` by the 6-byte storage and can pass 1.0 — a byte-saving "
+                                 "per residue (196608 B per DB vector): it exceeds `achieved` by the 46-bit storage and can pass 1.0 — a byte-saving "
                                  "figure, not a utilisation.  vs_measured_stream_ceiling: against 7.05 TB/s, what this GPU gives a read-once sequential "
                                  "stream (tools/ubench/stream_rate.hip; the guide's copy ceiling is 6.29).  traffic = PMC HBM bytes per launch "
                                  "(profiles/tensor_traffic.json), quoted only while the kernel source it was profiled on is unchanged.  step = the whole "

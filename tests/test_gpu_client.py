@@ -231,7 +231,7 @@ def test_hers_reference_dataset_full_ring(im):
 
 
 def test_full_size_2p20_properties(im):
-    """BASELINE's headline size on one GPU (2^20 vectors, 64 blocks, 32768 database ciphertexts, 148 GiB resident) through
+    """BASELINE's headline size on one GPU (2^20 vectors, 64 blocks, 32768 database ciphertexts, 142.5 GiB resident) through
     size-independent properties: (1) every one of the 2^20 decrypted scores within 1e-4 of plaintext cosine
     (src/main_accuracy.cpp:359-360); (2) index = planted matches, membership true; (3) additivity in the query ciphertext:
     similarity(qa + qb) decrypts to similarity(qa) + similarity(qb); (4) block independence (sender_diag.cpp:28-30): the score

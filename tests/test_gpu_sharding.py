@@ -495,7 +495,7 @@ def test_db_save_load_round_trip(im, tmp_path):
 
 
 def test_shard_group_full_size_2p20(im):
-    """BASELINE config 5's database (2^20 vectors, 64 blocks, 148 GiB resident) through the sharded sender in config 5's own shape,
+    """BASELINE config 5's database (2^20 vectors, 64 blocks, 142.5 GiB resident) through the sharded sender in config 5's own shape,
     EIGHT shards of 8 blocks (all on the one GPU; loop A's rotations shared out over the shards and exchanged): index batch (global block order), decrypted global indices and the membership ciphertext equal the single-context run's."""
     n = 1 << 20
     planted = [0, 12345, n // 2 + 3, n - 1]
