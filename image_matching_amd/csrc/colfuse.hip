@@ -190,6 +190,26 @@ DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[
         v[k] = ar.from_canon(r);
     }
 }
+// Pseudo-Mersenne targets (q_0 and the special primes, 2^60 - c): the two-word sum is FOLDED (IntP::fold_lh, four multiply-adds) to a
+// lazy representative below 2.07 2^60 instead of Barrett-reduced — with the dropped limb's residue (at most q) the forward
+// butterflies start below 3.1 q and reach 15.1 q at their first fold (bound 16 q).
+template <bool MDR>
+DEV void cf_convert(const IntP ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
+                    unsigned neg, u64 (&v)[16], bool nosrc) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u64 r = 0;
+        if (!nosrc) {
+            const CfSum a = cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f);
+            r = ar.fold_lh(a.L, a.H);
+        }
+        if (MDR) {
+            const u64 c = reduce64(um[k * 256], M);
+            r += ((neg >> k) & 1u) ? M.q - c : c;
+        }
+        v[k] = r;
+    }
+}
 template <bool MDR>
 DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
                     unsigned neg, double c60, double (&v)[16], bool nosrc) {
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         } else if ((T.pm_mask >> m) & 1u) {
             const IntP ar(M);
             u64 v[16];
-            cf_convert<IntP, MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            cf_convert<MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
             cf_forward<IntP>(ar, tw, ltw, lds, g, col, v, d);
         } else {
             const IntA ar(M);
@@ -395,6 +415,7 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
         }
         cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
     } else {
+        const bool pm = (T.pm_mask >> m) & 1u;
         u64 v[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -402,14 +423,23 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
             u64 mag;
             bool ng;
             convert_row(k, a, mag, ng);
-            u64 r = reduce128k(a.wide(), M);
-            if (MDR) {
-                const u64 c = reduce64(mag, M);
-                r = addmod(r, ng ? negmod(c, M.q) : c, M.q);
+            u64 r;
+            if (pm) {  // folded, lazy (cf_convert's pseudo-Mersenne form)
+                r = IntP(M).fold_lh(a.L, a.H);
+                if (MDR) {
+                    const u64 c = reduce64(mag, M);
+                    r += ng ? M.q - c : c;
+                }
+            } else {
+                r = reduce128k(a.wide(), M);
+                if (MDR) {
+                    const u64 c = reduce64(mag, M);
+                    r = addmod(r, ng ? negmod(c, M.q) : c, M.q);
+                }
             }
             v[k] = r;
         }
-        if ((T.pm_mask >> m) & 1u) cf_forward<IntP>(IntP(M), tw, ltw, lds, g, col, v, d);
+        if (pm) cf_forward<IntP>(IntP(M), tw, ltw, lds, g, col, v, d);
         else cf_forward<IntA>(IntA(M), tw, ltw, lds, g, col, v, d);
     }
 }

@@ -1189,7 +1189,7 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
         const double rot_acc = (double)dim * 2 * per_lp8 + (double)G * 3 * per_lp8;
         char n0[64], n1[64];
         snprintf(n0, sizeof n0, "k_hydia_tensor<%d, %d, true, false>", BPP, NW);
-        snprintf(n1, sizeof n1, h24 ? "k_hydia_tensor24<%d, %d>" : "k_hydia_tensor<%d, %d, true, true>", BPP, NW);
+        snprintf(n1, sizeof n1, h24 ? (L.bits46 ? "k_hydia_tensor24<%d, %d, true, true>" : "k_hydia_tensor24<%d, %d, false, false>") : "k_hydia_tensor<%d, %d, true, true>", BPP, NW);  // as rocprofv3 prints the instantiation
         if (L.packed && G <= 8) snprintf(n0, sizeof n0, "k_hydia_tensor_sk<%d, false>", G <= 2 ? 16 : 4);
         if (L.packed) {
             ledger_add(n0, (double)G * dim * 2 * per_lp8 + rot_acc);

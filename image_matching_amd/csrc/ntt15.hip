@@ -263,7 +263,9 @@ struct LoopAOperands {
         }
     }
 };
-template <bool SIX>
+// RED: how the 128-bit sums leave — 0 Barrett (any modulus), 1 / 2 pseudo-Mersenne folds (IntP): canonical / lazy below 3.07 2^60
+// (what the inverse transform's first two stages take: ntt_arith.h)
+template <bool SIX, int RED>
 DEV void loop_a_ip_int(const LoopAIp &la, const ModC &M, const unsigned char *kp, size_t set_bytes, int jd, unsigned idx, ulonglong2 &o0,
                        ulonglong2 &o1) {
     constexpr int N = 32768;
@@ -289,8 +291,14 @@ DEV void loop_a_ip_int(const LoopAIp &la, const ModC &M, const unsigned char *kp
         a2 += (u128)v1.x * k1.x;
         a3 += (u128)v1.y * k1.y;
     }
-    o0 = make_ulonglong2(reduce_lazy(a0, M, la.nd), reduce_lazy(a1, M, la.nd));
-    o1 = make_ulonglong2(reduce_lazy(a2, M, la.nd), reduce_lazy(a3, M, la.nd));
+    if (RED == 0) {
+        o0 = make_ulonglong2(reduce_lazy(a0, M, la.nd), reduce_lazy(a1, M, la.nd));
+        o1 = make_ulonglong2(reduce_lazy(a2, M, la.nd), reduce_lazy(a3, M, la.nd));
+    } else {
+        const IntP ar(M);
+        o0 = RED == 1 ? make_ulonglong2(ar.canon128(a0), ar.canon128(a1)) : make_ulonglong2(ar.fold128(a0), ar.fold128(a1));
+        o1 = RED == 1 ? make_ulonglong2(ar.canon128(a2), ar.canon128(a3)) : make_ulonglong2(ar.fold128(a2), ar.fold128(a3));
+    }
 }
 template <bool SIX>
 DEV void loop_a_ip_fp(const LoopAIp &la, const FpA &ar, const unsigned char *kp, size_t set_bytes, int jd, unsigned idx, ulonglong2 &o0,
@@ -326,6 +334,7 @@ DEV void loop_a_ip_fp(const LoopAIp &la, const FpA &ar, const unsigned char *kp,
     o0 = make_ulonglong2(ar.fin_fwd(a0), ar.fin_fwd(a1));
     o1 = make_ulonglong2(ar.fin_fwd(a2), ar.fin_fwd(a3));
 }
+template <int RED = 0>
 DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     constexpr int N = 32768;
     const unsigned char *key = reinterpret_cast<const unsigned char *>(la.keys[x]);
@@ -333,8 +342,8 @@ DEV void loop_a_inner_product(const LoopAIp &la, const ModC &M, int x, int p, in
     const bool pk = la.packed_nQ > 0, six = pk && j > 0 && j < la.packed_nQ;
     const size_t set_bytes = pk ? key_set_bytes(N, la.packed_nQ, la.nT) : (size_t)la.nT * N * 8;
     const unsigned char *kp = key + (pk ? key_limb_offset(N, la.packed_nQ, j) : (size_t)j * N * 8) + (size_t)idx * (six ? 6 : 8) + (size_t)p * set_bytes;
-    if (six) loop_a_ip_int<true>(la, M, kp, set_bytes, jd, idx, o0, o1);
-    else loop_a_ip_int<false>(la, M, kp, set_bytes, jd, idx, o0, o1);
+    if (six) loop_a_ip_int<true, RED>(la, M, kp, set_bytes, jd, idx, o0, o1);
+    else loop_a_ip_int<false, RED>(la, M, kp, set_bytes, jd, idx, o0, o1);
 }
 DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p, int slot, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     constexpr int N = 32768;
@@ -346,15 +355,19 @@ DEV void loop_a_inner_product_fp(const LoopAIp &la, const FpA &ar, int x, int p,
     if (six) loop_a_ip_fp<true>(la, ar, kp, set_bytes, jd, idx, o0, o1);
     else loop_a_ip_fp<false>(la, ar, kp, set_bytes, jd, idx, o0, o1);
 }
+// LAZY: the sums feed an inverse transform (any representative its first stages take), not an epilogue (canonical)
+template <bool LAZY>
 DEV void loop_a_inner_product(const LoopAIp &la, const IntA &, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
-    loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
+    loop_a_inner_product<0>(la, M, x, p, j, idx, o0, o1);
 }
+template <bool LAZY>
 DEV void loop_a_inner_product(const LoopAIp &la, const IntP &, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
-    loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
+    loop_a_inner_product<LAZY ? 2 : 1>(la, M, x, p, j, idx, o0, o1);
 }
+template <bool LAZY>
 DEV void loop_a_inner_product(const LoopAIp &la, const FpA &ar, const ModC &M, int x, int p, int j, unsigned idx, ulonglong2 &o0, ulonglong2 &o1) {
     if (la.fp) loop_a_inner_product_fp(la, ar, x, p, j, idx, o0, o1);
-    else loop_a_inner_product(la, M, x, p, j, idx, o0, o1);
+    else loop_a_inner_product<0>(la, M, x, p, j, idx, o0, o1);
 }
 // accumulator of the key-switching inner product fused into pass 2 (mode 4): 128-bit lazy integer sums for the 60-bit primes,
 // exactly reduced FP64 products for the primes below 2^47 (same canonical result)
@@ -368,15 +381,19 @@ struct IpAcc<IntA> {
     DEV static V canon(u64 v) { return v; }
     DEV void mac(const IntA &, V v, u64 key) { s += (u128)v * key; }
     DEV u64 fin(const IntA &, const ModC &M, int terms) const { return reduce_lazy(s, M, terms); }
+    DEV u64 fin_lazy(const IntA &ar, const ModC &M, int terms) const { return fin(ar, M, terms); }
 };
 template <>
 struct IpAcc<IntP> {
     typedef u64 V;
     u128 s = 0;
-    DEV static V prep(const IntP &ar, u64 c) { return ar.fin_fwd(c); }
+    // round 4: the transform's lazy output (below 9q) goes into the products as it is — at most four products below 2^124 — and the
+    // sum is folded (2^64 = 16c mod q) instead of Barrett-reduced: fin canonical, fin_lazy below 3.07 2^60 for the inverse transform
+    DEV static V prep(const IntP &, u64 c) { return c; }
     DEV static V canon(u64 v) { return v; }
     DEV void mac(const IntP &, V v, u64 key) { s += (u128)v * key; }
-    DEV u64 fin(const IntP &, const ModC &M, int terms) const { return reduce_lazy(s, M, terms); }
+    DEV u64 fin(const IntP &ar, const ModC &, int) const { return ar.canon128(s); }
+    DEV u64 fin_lazy(const IntP &ar, const ModC &, int) const { return ar.fold128(s); }
 };
 template <>
 struct IpAcc<FpA> {
@@ -389,6 +406,7 @@ struct IpAcc<FpA> {
     DEV static V canon(u64 v) { return FpA::u2d(v); }
     DEV void mac(const FpA &ar, V v, u64 key) { s += ar.mulmod2(v, FpA::u2d(key)); }
     DEV u64 fin(const FpA &ar, const ModC &, int) const { return ar.fin_fwd(s); }
+    DEV u64 fin_lazy(const FpA &ar, const ModC &M, int terms) const { return fin(ar, M, terms); }
 };
 template <int ST, class A>
 DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned idx, const ModC &M) {
@@ -397,7 +415,7 @@ DEV P2Pre p2_prefetch(const NttStore &st, const A &ar, int xp, int j, unsigned i
     r.has_ex = false;
     r.ex0 = r.ex1 = make_ulonglong2(0, 0);
     if (ST == 5) {
-        loop_a_inner_product(st.la, ar, M, xp >> 1, xp & 1, j, idx, r.in0, r.in1);
+        loop_a_inner_product<false>(st.la, ar, M, xp >> 1, xp & 1, j, idx, r.in0, r.in1);
     } else {
         const u64 *pi = st.in + ((size_t)xp * st.in_ls + j) * N + idx;
         r.in0 = *reinterpret_cast<const ulonglong2 *>(pi);
@@ -836,7 +854,14 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
                     for (int pp = 0; pp < 2; pp++) {
                         IpAcc<A> *ip = pp == 0 ? ipb : ipa;
-                        u64 f4[4] = {ip[0].fin(ar, M, NP + 1), ip[1].fin(ar, M, NP + 1), ip[2].fin(ar, M, NP + 1), ip[3].fin(ar, M, NP + 1)};
+                        u64 f4[4];
+                        if (ip_t != stp.ip.drop_l) {  // straight into the inverse transform: any representative its first two stages take
+#pragma unroll
+                            for (int k = 0; k < 4; k++) f4[k] = ip[k].fin_lazy(ar, M, NP + 1);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) f4[k] = ip[k].fin(ar, M, NP + 1);
+                        }
                         if (ip_t == stp.ip.drop_l) {  // workgroup-uniform: the limb the rescale drops — (sum P^{-1} + d_l)(x2), k_moddown_last_limb's arithmetic
                             u64 dv[4];
                             if (stp.ip.drop_has_prod) {  // d_p of the fused product at this limb
@@ -897,7 +922,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             for (int p = 0; p < NP; p++) {
                 ulonglong2 i0, i1;
                 if (ST == 5) {  // the transform's input is loop A's inner product for these four coefficients
-                    loop_a_inner_product(stp.la, ar, M, (xp0 + p) >> 1, (xp0 + p) & 1, slot, (unsigned)(B0 + e), i0, i1);
+                    loop_a_inner_product<true>(stp.la, ar, M, (xp0 + p) >> 1, (xp0 + p) & 1, slot, (unsigned)(B0 + e), i0, i1);
                 } else if (ST == 7) {  // ... is the dropped limb of the would-be ModDown output: (acc P^{-1} + addend)(x2), formed here
                     const int xq = xp0 + p;
                     const u64 *pa = stp.addend + (size_t)(xq >> 1) * stp.add_x + (size_t)(xq & 1) * stp.add_p + (size_t)stp.nl * 32768 + (B0 + e);
@@ -1017,8 +1042,9 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__r
 // workgroups are ordered so that the two kinds run side by side on every CU: groups of xb = 8 ciphertexts, inside a group the nP
 // special-prime rows spread evenly among the nl Q rows (Bresenham), inside a row x fastest (the 8 workgroups that share a key tile follow
 // each other; a tile is re-fetched once per group, from the Infinity Cache).
+// (two digits: held to four waves per SIMD — 128 registers; unbounded the folded reductions take 129 and the kernel loses 3 %)
 template <int ND>
-__global__ __launch_bounds__(256) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int xb, NttStore stp) {
+__global__ __launch_bounds__(256, ND == 2 ? 4 : 1) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int xb, NttStore stp) {
     constexpr bool SWZ = ND >= 3;  // three (or four) images: the unpadded, XOR-swizzled form buys a workgroup per CU (P2Lds)
     __shared__ u64 lds[ND][P2Lds<SWZ>::SIZE];
     const int nl = stp.ip.nl, nS = stp.ip.nE, nP = nS - nl;

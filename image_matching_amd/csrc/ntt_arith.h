@@ -73,6 +73,32 @@ struct IntP {
     DEV static T from_bits(u64 x) { return x; }
     DEV static u64 to_bits(T x) { return x; }
     DEV u64 fold(u64 x) const { return (x & ((1ull << 60) - 1)) + (u64)(unsigned)(x >> 60) * c; }
+    // Wide sums without a Barrett reduction (round 4): with 2^60 = c and 2^64 = 16c (mod q) a two-word sum folds to a lazy
+    // representative in four carry-free multiply-adds — the transforms take lazy operands anyway (forward: up to 12q before a
+    // stage; inverse: below 4q where two stages run to the next fold).
+    // L + H 2^60, H < 2^63 (the conversion sums of colfuse.hip: L < 2^63, H < 2^62 + 2^33): result below 2.07 2^60.
+    DEV u64 fold_lh(u64 L, u64 H) const {
+        const u64 m1 = (u64)(unsigned)(H >> 32) * c;  // < 2^55; m1 2^32 = (m1 >> 28) 2^60 + (m1 mod 2^28) 2^32
+        u64 acc = (L & ((1ull << 60) - 1)) + (u64)(unsigned)(L >> 60) * c;
+        acc += (u64)(unsigned)H * c;            // < 2^56
+        acc += (u64)(unsigned)(m1 >> 28) * c;   // < 2^51
+        return acc + ((u64)((unsigned)m1 & 0x0FFFFFFFu) << 32);  // + (< 2^60)
+    }
+    // ANY 128-bit z (the key-switching inner products: up to four products of a lazy value below 2^64 with a key residue): result
+    // below 3.07 2^60.
+    DEV u64 fold128(u128 z) const {
+        const u64 lo = (u64)z;
+        const unsigned c16 = c << 4;
+        const u64 t1 = (u64)(unsigned)(z >> 96) * c16;  // < 2^60; t1 2^32 split at 2^60 as above
+        u64 acc = (lo & ((1ull << 60) - 1)) + (u64)(unsigned)(lo >> 60) * c;
+        acc += (u64)(unsigned)(z >> 64) * c16;  // < 2^60
+        acc += (u64)(unsigned)(t1 >> 28) * c;   // < 2^56
+        return acc + ((u64)((unsigned)t1 & 0x0FFFFFFFu) << 32);  // + (< 2^60)
+    }
+    DEV u64 canon128(u128 z) const {
+        const u64 x = fold(fold128(z));  // <= 2^60 + 3c < 2q
+        return x >= q ? x - q : x;
+    }
     // Shoup product x w - hi' q modulo 2^64 for ANY 64-bit x, in [0, 4q): -hi' q = hi' c - hi' 2^60, one 32 x 32 multiply-add onto
     // x w, and the high dword takes hi1 c - (hi0 << 28) — two multiplies instead of the three of a general 64 x 64 low product, no
     // borrow chain
