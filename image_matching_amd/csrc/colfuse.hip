@@ -119,10 +119,9 @@ DEV double cf_fold(const FpA &ar, const CfSum a, double c60) {
 }
 
 // split: leave the residues in the 30 + 30 bit form the conversion sums take (conversion sources; not the dropped limb)
-DEV void cf_inverse_any(const NttTables &T, int m, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs, u64 (&y)[16],
-                        bool split) {
-    const ModC M = T.mod[m];
-    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+DEV void cf_inverse_any(const NttTables &T, int m, const ModC &M, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs,
+                        u64 (&y)[16], bool split) {
+    const bool fp = (T.fp_mask >> m) & 1u;
     const ulonglong2 *__restrict__ tw = (fp ? T.itwf : T.itwp) + (size_t)m * 32768;
     if (fp) cf_inverse<FpA>(FpA(M), tw, ltw, lds, g, col, sc, scs, y);
     else if ((T.pm_mask >> m) & 1u) cf_inverse<IntP>(IntP(M), tw, ltw, lds, g, col, sc, scs, y);
@@ -271,12 +270,12 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         for (int s = 0; s < HY_CF_SRC; s++)
             if (s < cf.nk) {
                 const int m = cf.smod[s];
-                const bool fp = T.twf != nullptr && T.mod[m].ks + 2 <= 47;
+                const bool fp = (T.fp_mask >> m) & 1u;
                 sltw[s * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
             }
         if (MDR) {
             const int m = cf.umod;
-            const bool fp = T.twf != nullptr && T.mod[m].ks + 2 <= 47;
+            const bool fp = (T.fp_mask >> m) & 1u;
             sltw[HY_CF_SRC * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
         }
     }
@@ -287,20 +286,20 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
     // ---- pass 1' of every source: raw -> canonical coefficient-form residues, in place in y / um (the dropped limb first: its
     // registers are free again before the others are transformed)
     if (MDR) {
-        cf_inverse_any(T, cf.umod, sltw + HY_CF_SRC * 128, CF_NEXT_IMAGE(), g, col, cf.usc, cf.usc_sh, um, false);
+        cf_inverse_any(T, cf.umod, cf.uM, sltw + HY_CF_SRC * 128, CF_NEXT_IMAGE(), g, col, cf.usc, cf.usc_sh, um, false);
 #pragma unroll
         for (int k = 0; k < 16; k++) umem[k * 256] = um[k];
 #pragma unroll
         for (int s = 2; s < HY_CF_SRC; s++) load_source(s);
     }
-    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], sltw, CF_NEXT_IMAGE(), g, col, cf.ssc[0], cf.ssc_sh[0], y[0], true);
-    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], sltw + 128, CF_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], true);
-    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], sltw + 256, CF_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], true);
-    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], sltw + 384, CF_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], true);
+    if (0 < cf.nk) cf_inverse_any(T, cf.smod[0], cf.sM[0], sltw, CF_NEXT_IMAGE(), g, col, cf.ssc[0], cf.ssc_sh[0], y[0], true);
+    if (1 < cf.nk) cf_inverse_any(T, cf.smod[1], cf.sM[1], sltw + 128, CF_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], true);
+    if (2 < cf.nk) cf_inverse_any(T, cf.smod[2], cf.sM[2], sltw + 256, CF_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], true);
+    if (3 < cf.nk) cf_inverse_any(T, cf.smod[3], cf.sM[3], sltw + 384, CF_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], true);
     // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
     unsigned neg = 0;
     if (MDR) {
-        const ModC Ml = T.mod[cf.l];
+        const ModC Ml = cf.lM;
         const u64 half = Ml.q >> 1;
         CfConst fl;
 #pragma unroll
@@ -315,13 +314,21 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
             }
     }
     // ---- every target of this slice: conversion, pass 1, raw image out
+    // (every source load has been consumed by its transform; said explicitly, because the compiler cannot prove it for a source the
+    // map does not have and would otherwise wait — at the top of EVERY target — for "the loads" with vmcnt(0), i.e. for the previous
+    // target's sixteen stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    // (the twiddle request below is made and stored by all 256 lanes — the upper half duplicates the lower — so that no path leaves a
+    // load pending either)
+#define CF_STORE_LTW() ltw[t & 127] = ltv
     for (int tt = t_lo; tt < t_hi; tt++) {
+        // (every constant of the target straight off the map — one batch of scalar loads; the phase-B twiddles are requested here and
+        // stored to LDS after the conversion, where their latency has passed)
         const int m = cf.tmod[tt];
-        const ModC M = T.mod[m];
-        const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+        const ModC M = cf.tM[tt];
+        const bool fp = (T.fp_mask >> m) & 1u;
         const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
         ulonglong2 *ltw = tltw + (tt & 1) * 128;
-        if (t < 128) ltw[t] = tw[t];
         u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;  // cf_forward adds the lane's column
         u64 *lds = CF_NEXT_IMAGE();
         // the sources are loop-invariant: without this the compiler hoists per-source subexpressions of the conversion out of the target
@@ -333,20 +340,24 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         CfConst f;
 #pragma unroll
         for (int s = 0; s < HY_CF_SRC; s++) f.set(s, s < cf.nk ? cf.f[s][tt] : 0);
+        const ulonglong2 ltv = tw[t & 127];
         if (fp) {
             const FpA ar(M);
             double v[16];
             cf_convert<MDR>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v, MDR && cf.nk == 0);
+            CF_STORE_LTW();
             cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
         } else if ((T.pm_mask >> m) & 1u) {
             const IntP ar(M);
             u64 v[16];
             cf_convert<MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            CF_STORE_LTW();
             cf_forward<IntP>(ar, tw, ltw, lds, g, col, v, d);
         } else {
             const IntA ar(M);
             u64 v[16];
             cf_convert<IntA, MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            CF_STORE_LTW();
             cf_forward<IntA>(ar, tw, ltw, lds, g, col, v, d);
         }
     }
@@ -369,8 +380,8 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
     const int xp = blockIdx.y, c0 = blockIdx.x * 32;
     const u64 *sb = src + (size_t)xp * so + c0 + col;
     const int m = cf.tmod[tt];
-    const ModC M = T.mod[m];
-    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const ModC M = cf.tM[tt];  // (off the map: no dependent load between the target's id and its constants)
+    const bool fp = (T.fp_mask >> m) & 1u;
     const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
     if (t < 128) ltw[t] = tw[t];
     CfConst f, fl;
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
         sp[s] = sb + (size_t)cf.srow[on ? s : 0] * N;  // absent sources re-read source 0 against a zero constant
     }
     const u64 *su = MDR ? sb + (size_t)cf.urow * N : sb;
-    const ModC Ml = T.mod[MDR ? cf.l : m];
+    const ModC Ml = MDR ? cf.lM : M;
     u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;
     // one row at a time: the (up to five) operands of row g + 8k are loaded where they are used; a holds sum_s y_s f_s, the dropped
     // limb's centred residue (MDR) is formed from the same operands

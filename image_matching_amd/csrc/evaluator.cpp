@@ -77,8 +77,17 @@ const Context::ModUpPlan &Context::modup_plan(int nl) {
 const Context::CfPlan &Context::cf_plan_store(const std::string &key, std::vector<ColFuse> &&maps) {
     CfPlan pl;
     pl.host = std::move(maps);
-    for (ColFuse &cf : pl.host)
-        for (int t = 0; t < cf.nt; t++) cf.t60[t] = (1ull << 60) % q[cf.tmod[t]];
+    for (ColFuse &cf : pl.host) {
+        for (int t = 0; t < cf.nt; t++) {
+            cf.t60[t] = (1ull << 60) % q[cf.tmod[t]];
+            cf.tM[t] = mod[cf.tmod[t]];
+        }
+        for (int s = 0; s < cf.nk; s++) cf.sM[s] = mod[cf.smod[s]];
+        if (cf.mdr) {
+            cf.uM = mod[cf.umod];
+            cf.lM = mod[cf.l];
+        }
+    }
     HIP_CHECK(hipMalloc((void **)&pl.dev, sizeof(ColFuse) * pl.host.size()));
     HIP_CHECK(hipMemcpy(pl.dev, pl.host.data(), sizeof(ColFuse) * pl.host.size(), hipMemcpyHostToDevice));
     return cf_plans.emplace(key, std::move(pl)).first->second;

@@ -177,6 +177,10 @@ struct ColFuse {
     u64 f[HY_CF_SRC][HY_CF_TGT];           // conversion constants: target t = sum_k y_k f[k][t] mod q_tmod[t]
     u64 fl[HY_CF_SRC];                     // mdr: constants of the dropped limb, y_l = u - sum_k y_k fl[k] mod q_l
     u64 t60[HY_CF_TGT];                    // 2^60 mod q_tmod[t] (the FP64 fold of the conversion sums; filled by cf_plan_store)
+    ModC sM[HY_CF_SRC], uM, lM;            // the same for the sources, u and the dropped limb
+    ModC tM[HY_CF_TGT];                    // the targets' modulus constants (a copy of NttTables::mod[tmod[t]], filled by cf_plan_store): a
+                                           // target's constants then come with ONE batch of scalar loads off the map instead of a chain of
+                                           // dependent ones (tmod -> mod[] -> kind -> tables) at the head of every target
 };
 
 #include "db_layout.h"  // DbLayout, db_limb_offset, db_offset (host-checkable: tests/csrc/db_layout_check.cpp)

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_ntt15_p1(NttTables T, const u64 *__rest
     __shared__ ulonglong2 ltw[128];
     const int y = blockIdx.y, x = y / nsl, slot = slot0 + (y - x * nsl), m = sel.mod[slot];  // slots [slot0, slot0 + nsl) of sel
     const ModC M = T.mod[m];
-    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const bool fp = (T.fp_mask >> m) & 1u;  // the host's copy of the rule "FP64 tables present and q < 2^47": a kernel argument, so neither the
+                                             // branch nor the twiddle addresses wait for the modulus constants to arrive
     const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
     const int c0 = blockIdx.x * 32;
     const u64 *s = src + (size_t)x * so + (size_t)slot * N + c0;
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : (!INV && ST == 10) ? 4
     const int y = blockIdx.y;
     const int xp = y / nsl, slot = slot0 + (y - xp * nsl), m = sel.mod[slot];
     const ModC M = T.mod[m];
-    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const bool fp = (T.fp_mask >> m) & 1u;
     const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
     const int B0 = blockIdx.x * 2048;
     const u64 *s[NP];
@@ -1004,7 +1005,7 @@ DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t
     constexpr int N = 32768;
     const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
     const ModC M = T.mod[m];
-    const bool fp = T.twf != nullptr && M.ks + 2 <= 47;
+    const bool fp = (T.fp_mask >> m) & 1u;
     const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
     const int B0 = bx * 2048;
     const int own_d = OWN ? t / stp.ip.alpha : (1 << 30);
