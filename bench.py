@@ -177,11 +177,54 @@ def git_head():
         return ""
 
 
+def stream_ceiling():
+    """what this GPU gives a read-once sequential stream in loop B's own access pattern (tools/ubench/stream_rate.hip): the
+    "workgroup-sequential layout" figure of the newest committed profiles/r*/stream_rate.txt -> (GB/s, file), or (None, None)"""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "stream_rate.txt")), reverse=True):
+        try:
+            m = re.search(r"^\s*workgroup-sequential layout:\s*([0-9.]+) TB/s", open(path).read(), re.M)
+        except OSError:
+            continue
+        if m:
+            return float(m.group(1)) * 1e3, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def model_step(log2n_total, world, mode):
+    """DESIGN.md section 7's prediction of one multi-GPU step from the committed ONE-GPU components (profiles/scaling_model.json):
+    what the first SCALE run is to be compared with, term by term.  mode: "local" (the auto rule's baby-step / giant-step split, a short
+    loop A per rank), "replicated" (every rank recomputes the 511 rotations), "split" (loop A shared out + all-gather of 3 GiB)."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "scaling_model.json")))
+        row = m["log2n"][str(log2n_total)][str(world)]
+    except (OSError, KeyError, ValueError):
+        return None
+    g = m["gather_sync_ms"]
+    out = {"source": "profiles/scaling_model.json (" + m["source"] + ")", "mode": mode, "unmeasured_on_multi_gpu_hardware": True}
+    if mode == "local" and "whole_query_auto_split_ms" in row:
+        terms = {"compute_ms": row["whole_query_auto_split_ms"], "comm_ms": g}
+    elif mode == "split":
+        ag = {k: (world - 1) / world * m["rotations_bytes"] / max(world - 1, 1) / (v * 1e9) * 1e3 for k, v in m["xgmi_link_GBs"].items()}
+        terms = {"compute_ms": row["loop_a_share_ms"] + row["rest_on_given_rotations_ms"], "comm_ms": g + ag["high"],
+                 "loop_a_share_ms": row["loop_a_share_ms"], "rest_on_given_rotations_ms": row["rest_on_given_rotations_ms"],
+                 "rotations_all_gather_ms_at_153_GBs_per_link": round(ag["high"], 3), "rotations_all_gather_ms_at_76.8_GBs_per_link": round(ag["low"], 3)}
+    else:
+        terms = {"compute_ms": row["whole_query_replicated_loop_a_ms"], "comm_ms": g}
+    terms["gather_and_sync_ms"] = g
+    out["terms"] = terms
+    out["predicted_ms_per_step"] = round(terms["compute_ms"] + terms["comm_ms"], 3)
+    return out
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.  The children are plain
-    subprocesses of this interpreter (never os.exec*), started BEFORE this process has made any GPU or HIP call (it never makes
-    one), one per LOCAL_RANK, rendezvous on 127.0.0.1.  Rank 0's stdout is captured and its JSON line relayed; the other ranks'
-    stdout goes to stderr.  The first rank that fails takes the others down (by exact PID) and its exit code is returned."""
+    subprocesses of this interpreter (never os.exec*); this process only ever COUNTS devices (torch.cuda.device_count(), which creates
+    no context) and never execs, one child per LOCAL_RANK, rendezvous on 127.0.0.1.  Rank 0's stdout is captured and its JSON line
+    relayed; the other ranks' stdout goes to stderr.  The first rank that fails takes the others down (by exact PID) and its exit code
+    is returned; once rank 0 has finished the others get HYDIA_BENCH_STRAGGLER_S seconds (default 120) to follow, then are stopped
+    and the run counts as failed (code 5)."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -202,15 +245,21 @@ def launch_ranks(n, argv):
         rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
         rd.start()
         live = set(range(n))
+        grace, rank0_done = float(os.environ.get("HYDIA_BENCH_STRAGGLER_S", "120")), None
         while live and rc == 0:
             for r in sorted(live):
                 c = procs[r].poll()
                 if c is not None:
                     live.discard(r)
+                    if r == 0:
+                        rank0_done = time.time()
                     if c != 0:
                         rc = c if c > 0 else 128 - c
                         sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
                         break
+            if rc == 0 and live and rank0_done is not None and time.time() - rank0_done > grace:
+                rc = 5
+                sys.stderr.write("bench.py: rank 0 finished %.0f s ago and rank(s) %s still run; stopping them\n" % (grace, sorted(live)))
             time.sleep(0.05)
         if rc:
             for r in live:
@@ -412,6 +461,30 @@ def main():
     elapsed = timed(sender, qc, args.steps)
 
     ms_tensor, launches = cc.kernel_time("hydia_tensor")
+    # N > 1: where a step goes, per rank (outside the timed region: the phases are fenced, which the timed steps are not)
+    split_report = None
+    if multi:
+        k_i = 3
+        sender.timing = {}
+        dt_i = timed(sender, qc, k_i)
+        mine = {k: v / k_i for k, v in sender.timing.items() if k != "calls"}
+        sender.timing = None
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        if rank == 0:
+            comm = [sum(d.get(k, 0.0) for k in sender.COMM_PHASES) for d in per_rank]
+            comp = [sum(d.get(k, 0.0) for k in sender.COMPUTE_PHASES) for d in per_rank]
+            names = sorted({k for d in per_rank for k in d})
+            split_report = {
+                "what": "%d further steps with every phase of DistDiagonalSender fenced (library stream + torch stream) and timed on the host, "
+                        "per rank; comm = query_broadcast + form_check + rotations_all_gather + result_gather (a rank's wait for slower ranks "
+                        "is inside its collectives), compute = loop_a_share + local_matvec_comparator" % k_i,
+                "instrumented_ms_per_step": round(dt_i / k_i * 1e3, 3),
+                "comm_ms": {"max": round(max(comm), 3), "min": round(min(comm), 3)},
+                "compute_ms": {"max": round(max(comp), 3), "min": round(min(comp), 3)},
+                "phases_ms": {k: {"max": round(max(d.get(k, 0.0) for d in per_rank), 3), "min": round(min(d.get(k, 0.0) for d in per_rank), 3)} for k in names},
+                "rank0_sum_ms": round(comm[0] + comp[0], 3),
+                "per_rank_ms": [{k: round(v, 3) for k, v in d.items()} for d in per_rank]}
     # secondary figure of SURVEY 8d (outside the timed region): computeSimilarity alone = loop A + loop B + relin + rescale
     ms_similarity = None
     if not multi:
@@ -558,17 +631,26 @@ def main():
                          "traffic": traffic, "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
                          "traffic_meta": traffic_meta,
                          "algorithmic_frac": achieved / HBM_PEAK_GBS, "algorithmic_achieved": achieved, "algorithmic_bytes_per_launch": algo_bytes,
-                         "vs_measured_stream_ceiling": wire / 7050.0,
+                         "vs_measured_stream_ceiling": (wire / stream_ceiling()[0]) if stream_ceiling()[0] else None,
+                         "stream_ceiling": {"GBs": stream_ceiling()[0], "source": stream_ceiling()[1]},
                          "step": step_roofline,
                          "note": "achieved/frac = bytes RESIDENT in HBM that one loop-B pass has to move (database with 46- or 48-bit residues for the "
                                  "45/46-bit limbs, see config.workload, + rotated queries + accumulators at 8 bytes: every byte once) / mean pass duration (HIP events on "
                                  "the library's stream) / 8 TB/s: a utilisation, <= 1.  algorithmic_* = the same pass priced by SURVEY 8d at 8 bytes "
                                  "per residue (196608 B per DB vector): it exceeds `achieved` by the 46-bit storage and can pass 1.0 — a byte-saving "
-                                 "figure, not a utilisation.  vs_measured_stream_ceiling: against 7.05 TB/s, what this GPU gives a read-once sequential "
-                                 "stream (tools/ubench/stream_rate.hip; the guide's copy ceiling is 6.29).  traffic = PMC HBM bytes per launch "
+                                 "figure, not a utilisation.  vs_measured_stream_ceiling: against stream_ceiling.GBs, what this GPU gives a read-once sequential "
+                                 "stream in this access pattern (tools/ubench/stream_rate.hip, read from stream_ceiling.source; the guide's copy ceiling is 6.29).  traffic = PMC HBM bytes per launch "
                                  "(profiles/tensor_traffic.json), quoted only while the kernel source it was profiled on is unchanged.  step = the whole "
                                  "indexScenario: inherent bytes of every operation (byte ledger, op:* entries) / ms_per_step"},
         }
+        if split_report is not None:
+            mode = "local" if (loop_a and loop_a["mode"] == "local") else ("split" if getattr(sender, "rotation_split", False) else "replicated")
+            out["comm_ms"], out["compute_ms"] = split_report["comm_ms"], split_report["compute_ms"]
+            out["step_split"] = split_report
+            out["loop_a_mode"] = mode
+            out["model"] = model_step(n_total.bit_length() - 1, world, mode) if strong or world == 1 else None
+            if out["model"]:
+                out["model"]["measured_ms_per_step"] = round(ms_step, 3)
         if weak is not None:
             out["config"]["secondary"] = {"weak_scaling": weak}
         if ms_similarity is not None:

@@ -634,6 +634,23 @@ struct P2Lds {
     DEV static int at(int blk, int row, int pos) { return SWZ ? blk * 256 + row * 32 + (pos ^ (row << 2)) : blk * 288 + row * 36 + pos; }
 };
 
+// Round 5: pass 2 is WAVE-SYNCHRONOUS.  A 256-coefficient block belongs to one half-wave (blk = t >> 5) in EVERY phase — phase C takes the
+// two groups of four consecutive coefficients 4w + 128 hh of its own block instead of 4t + 1024 hh of the workgroup's chunk — so every
+// LDS exchange is between lanes of one wave: the LDS executes a wave's instructions in order, a ds_read after a ds_write needs no
+// s_barrier, and the four waves of a workgroup never wait for each other.  Same butterflies on the same operands: bit-identical.
+// (-DHYDIA_P2_WG_SYNC builds round 4's chunk-wide phase C with its five barriers: tools/ab/ A/B builds.)
+#ifdef HYDIA_P2_WG_SYNC
+DEV void p2_sync() { __syncthreads(); }
+DEV int p2_elem(int t, int hh) { return 4 * t + 1024 * hh; }
+#else
+DEV void p2_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler-only at this scope: LDS accesses stay on their side of the exchange
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DEV int p2_elem(int t, int hh) { return (t >> 5) * 256 + 4 * (t & 31) + 128 * hh; }
+#endif
+
 // phases B' and A' of the inverse second pass for NPI polynomials whose phase-C' output sits in lds (caller synchronised)
 template <class A, int NPI, bool SWZ = false>
 DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[P2Lds<SWZ>::SIZE], u64 *const *d, int t, int B0) {
@@ -672,7 +689,7 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
             }
         }
     }
-    __syncthreads();
+    p2_sync();
     // phase A': strides 32, 64, 128
     {
         const TW W7 = A::tw(tw[128 + bg]);
@@ -747,7 +764,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 }
             }
         }
-        __syncthreads();
+        p2_sync();
         // phase B: coefficients blk*256 + 32a + 4k + b ; stages 10,11,12 (strides 16, 8, 4)
         {
             const int ib = 8 * bg + a;
@@ -782,14 +799,14 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
             for (int hh = 0; hh < (SPLIT ? 1 : 2); hh++)
 #pragma unroll
-                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024 * hh), M);
-            if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t));
+                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem(t, hh)), M);
+            if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem(t, 0)));
         }
-        __syncthreads();
+        p2_sync();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int e = 4 * t + 1024 * hh, u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
+            const int e = p2_elem(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
             // mode 4: lazy 128-bit sums of value * key over the digits this workgroup transforms (+ the limb's own digit)
@@ -799,8 +816,8 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             const int ip_own = (stp.ip.own && ip_t < stp.ip.nl) ? ip_t / stp.ip.alpha : (1 << 30);
             if (SPLIT && hh == 1) {
 #pragma unroll
-                for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + 4 * t + 1024), M);
-                if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + 4 * t + 1024));
+                for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem(t, 1)), M);
+                if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem(t, 1)));
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) {
@@ -909,14 +926,14 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             }
         }
         if (ST == 6) {
-            __syncthreads();
+            p2_sync();
             p2_inverse_BA<A, 2, SWZ>(ar, itw, lds, dinv, t, B0);
         }
     } else {
         // phase C': strides 1, 2
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int e = 4 * t + 1024 * hh, u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
+            const int e = p2_elem(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
 #pragma unroll
@@ -963,7 +980,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 lds[p][la + 2] = A::to_bits(c2); lds[p][la + 3] = A::to_bits(c3);
             }
         }
-        __syncthreads();
+        p2_sync();
         p2_inverse_BA<A, NP, SWZ>(ar, tw, lds, d, t, B0);
     }
 }

@@ -166,6 +166,9 @@ class DistDiagonalSender:
         first, last = shard_vectors(n_total, cc.slots, world, rank)
         self.local = (make_sender or _h.DiagonalSender)(cc, last - first) if self.hi > self.lo else None
         self._bufs = {}
+        # timing (bench.py's instrumented steps, outside its timed region): a dict switches it on — every phase of a scenario call is
+        # then fenced (library stream + torch's stream) on both sides and its host time added under its name, calls counted in "calls"
+        self.timing = None
         # Loop A: option A = every rank computes all 511 rotations itself; option B (rotation_split) = rank k of the K
         # ranks that hold blocks computes the contiguous range shard_blocks(dim, K, k) and the ranges are all-gathered (3 GiB in all
         # over xGMI), so the node does loop A's work once instead of once per GPU.  Same ciphertexts either way.
@@ -191,7 +194,7 @@ class DistDiagonalSender:
 
     def _agree_form(self):
         """(collective) every rank's resident (kind, babies); the block-holding ranks must hold ONE form.  Run at construction and
-        again by the first scenario call after the local database changed (every rank re-enrols together or not at all)."""
+        again — on every rank, from _local — by the first scenario call after ANY rank's database changed (_forms_changed)."""
         mine = self._local_form()
         forms = [mine]
         if self.world > 1 and hasattr(self.cc, "db_kind"):
@@ -215,9 +218,40 @@ class DistDiagonalSender:
         self.rotation_split = self.rotation_split and self._want_split and not self.bsgs
 
     def refresh_form(self):
-        """(collective: every rank) re-read the mat-vec form of the resident databases after a re-enrolment / load / re-declaration"""
+        """(collective: every rank) re-read the mat-vec form of the resident databases after a re-enrolment / load / re-declaration.
+        The scenario calls do this themselves when any rank's form changed; calling it explicitly moves the cost out of the first query."""
         self.rotation_split = self._want_split
         self._agree_form()
+
+    # ---- per-phase timing of a scenario call (see __init__)
+    COMM_PHASES = ("query_broadcast", "form_check", "rotations_all_gather", "result_gather")
+    COMPUTE_PHASES = ("loop_a_share", "local_matvec_comparator")
+
+    def _fence(self):
+        if hasattr(self.cc, "sync"):
+            self.cc.sync()
+        if self.staging == "device":
+            self.torch.cuda.synchronize()
+
+    class _Phase:
+        def __init__(self, snd, name):
+            self.snd, self.name = snd, name
+
+        def __enter__(self):
+            if self.snd.timing is not None:
+                import time
+                self.snd._fence()
+                self.t0 = time.perf_counter()
+
+        def __exit__(self, *exc):
+            if self.snd.timing is not None and exc[0] is None:
+                import time
+                self.snd._fence()
+                self.snd.timing[self.name] = self.snd.timing.get(self.name, 0.0) + (time.perf_counter() - self.t0) * 1e3
+            return False
+
+    def _phase(self, name):
+        return DistDiagonalSender._Phase(self, name)
 
     # ---- buffers: int64 tensors that mirror [count][poly][limb][N] residues
     def _buf(self, key, n):
@@ -298,60 +332,89 @@ class DistDiagonalSender:
         lo, hi = self.rot_ranges.get(self.rank, (0, 0))
         scale = self._bufs["q_scale"]
         if self.staging == "device":
-            if hi > lo:
-                self.local.rotateQueryRangeInto(q, lo, hi - lo, full.data_ptr() + lo * per * 8)
-            cc.sync()  # the slice is written on the library's stream; the collective runs on torch's
-            if self.rot_even:
-                self.dist.all_gather_into_tensor(full, full[lo * per:hi * per])
-            else:
-                cnt = max(h - l for l, h in self.rot_ranges.values())
-                send = self._buf("rot_send", cnt * per)
+            with self._phase("loop_a_share"):
                 if hi > lo:
-                    send[:(hi - lo) * per].copy_(full[lo * per:hi * per])
-                recv = [self._buf("rot_recv%d" % r, cnt * per) for r in range(self.world)]
-                self.dist.all_gather(recv, send)
-                for r, (l, h) in self.rot_ranges.items():
-                    if r != self.rank and h > l:
-                        full[l * per:h * per].copy_(recv[r][:(h - l) * per])
-            self.torch.cuda.current_stream().synchronize()  # the library reads `full` from its own stream
+                    self.local.rotateQueryRangeInto(q, lo, hi - lo, full.data_ptr() + lo * per * 8)
+                cc.sync()  # the slice is written on the library's stream; the collective runs on torch's
+            with self._phase("rotations_all_gather"):
+                self._all_gather_rotations_device(full, lo, hi, per)
             return cc.ct_view_device(full.data_ptr(), dim, 2, cc.nQ, scale, keepalive=full) if self.local is not None else None
         # host staging (gloo): the same steps through host tensors
         cnt = max([h - l for l, h in self.rot_ranges.values()] + [1])
         send = self._buf("rot_send", cnt * per)
-        if hi > lo:
-            a = self.local.rotateQueryRange(q, lo, hi - lo).export().reshape(-1).view(np.int64)
-            send[:a.size] = self.torch.from_numpy(a)
-        recv = [self._buf("rot_recv%d" % r, cnt * per) for r in range(self.world)]
-        self.dist.all_gather(recv, send)
+        with self._phase("loop_a_share"):
+            if hi > lo:
+                a = self.local.rotateQueryRange(q, lo, hi - lo).export().reshape(-1).view(np.int64)
+                send[:a.size] = self.torch.from_numpy(a)
+        with self._phase("rotations_all_gather"):
+            recv = [self._buf("rot_recv%d" % r, cnt * per) for r in range(self.world)]
+            self.dist.all_gather(recv, send)
+            if self.local is not None:
+                for r, (l, h) in self.rot_ranges.items():
+                    if h > l:
+                        full[l * per:h * per] = recv[r][:(h - l) * per]
         if self.local is None:
             return None
-        for r, (l, h) in self.rot_ranges.items():
-            if h > l:
-                full[l * per:h * per] = recv[r][:(h - l) * per]
         return cc.import_ct(full.numpy().view(np.uint64).reshape(dim, 2, cc.nQ, cc.N), scale)
 
+    def _all_gather_rotations_device(self, full, lo, hi, per):
+        if self.rot_even:
+            self.dist.all_gather_into_tensor(full, full[lo * per:hi * per])
+        else:
+            cnt = max(h - l for l, h in self.rot_ranges.values())
+            send = self._buf("rot_send", cnt * per)
+            if hi > lo:
+                send[:(hi - lo) * per].copy_(full[lo * per:hi * per])
+            recv = [self._buf("rot_recv%d" % r, cnt * per) for r in range(self.world)]
+            self.dist.all_gather(recv, send)
+            for r, (l, h) in self.rot_ranges.items():
+                if r != self.rank and h > l:
+                    full[l * per:h * per].copy_(recv[r][:(h - l) * per])
+        self.torch.cuda.current_stream().synchronize()  # the library reads `full` from its own stream
+
+    def _forms_changed(self):
+        """(collective: every rank, every scenario call) has ANY rank's resident database changed form since the ranks last agreed?
+        One word, max-reduced: a rank that holds no block cannot see that the others re-enrolled, and a rank that raised on its own
+        while the others entered the next collective would leave them hanging until the backend's timeout."""
+        mine = 1 if self._local_form() != self._form else 0
+        if self.world == 1:
+            return bool(mine)
+        t = self._buf("chg", 1)
+        t.fill_(mine)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
     def _local(self, fn_name, q):
-        if self._local_form() != self._form:
-            # re-enrolled, loaded or re-declared since the ranks last agreed.  Agreeing again is a collective, and a rank that holds no
-            # block cannot see that the others changed — so it is never started from here: every rank calls refresh_form() (or builds a
-            # new sender) after the databases change
-            raise RuntimeError("DistDiagonalSender: the resident database changed since the ranks agreed on its form (%s -> %s); call "
-                               "refresh_form() on EVERY rank (or construct a new sender) after re-enrolling" % (self._form, self._local_form()))
+        with self._phase("form_check"):
+            changed = self._forms_changed()
+        if changed:
+            # enrolled after the sender was built, re-enrolled, loaded or re-declared: every rank learns of it in the same call and the
+            # ranks agree again (a collective, entered by all of them here).  Disagreeing forms raise ValueError on EVERY rank.
+            self.refresh_form()
         if self.rotation_split and self.bsgs:
             raise ValueError("rotation_split (loop A shared out over the ranks) needs hoisted databases; the resident ones are pre-rotated "
                              "for %s babies" % self.babies)
         if self.rotation_split and not self.bsgs and len(self.active) > 1:
             rot = self._gathered_rotations(q)
-            return getattr(self.local, fn_name + "Rotated")(rot) if self.local is not None else None
-        return getattr(self.local, fn_name)(q) if self.local is not None else None
+            with self._phase("local_matvec_comparator"):
+                return getattr(self.local, fn_name + "Rotated")(rot) if self.local is not None else None
+        with self._phase("local_matvec_comparator"):  # (loop A recomputed by this rank is part of it)
+            return getattr(self.local, fn_name)(q) if self.local is not None else None
+
+    def _scenario(self, key, fn_name, query_cipher):
+        if self.timing is not None:
+            self.timing["calls"] = self.timing.get("calls", 0) + 1
+        with self._phase("query_broadcast"):
+            q = self._bcast_query(query_cipher)
+        res = self._local(fn_name, q)
+        with self._phase("result_gather"):
+            return self._gather_blocks(key, res)
 
     def computeSimilarity(self, query_cipher):
-        q = self._bcast_query(query_cipher)
-        return self._gather_blocks("sim", self._local("computeSimilarity", q))
+        return self._scenario("sim", "computeSimilarity", query_cipher)
 
     def indexScenario(self, query_cipher):
-        q = self._bcast_query(query_cipher)
-        return self._gather_blocks("idx", self._local("indexScenario", q))
+        return self._scenario("idx", "indexScenario", query_cipher)
 
     def membershipScenario(self, query_cipher):
         q = self._bcast_query(query_cipher)

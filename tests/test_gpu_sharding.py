@@ -195,6 +195,7 @@ class ThreadDist:
 
     class ReduceOp:
         SUM = "sum"
+        MAX = "max"
 
     def __init__(self, world):
         import threading
@@ -242,6 +243,11 @@ class ThreadDist:
         assert op == self.ReduceOp.SUM
         self.slots[self.local.rank] = dict(t=t)
         self._run(lambda r: [t.add_(self.slots[k]["t"]) for k in range(self.world) if k != dst] if r == dst else None)
+
+    def all_reduce(self, t, op):
+        assert op == self.ReduceOp.MAX
+        self.slots[self.local.rank] = dict(t=t.clone())  # a snapshot: every rank reads every operand and overwrites its own
+        self._run(lambda r: t.copy_(self.torch.stack([self.slots[k]["t"] for k in range(self.world)]).max(0).values))
 
     def all_gather_into_tensor(self, out, inp):
         m = inp.numel()

@@ -165,3 +165,80 @@ def test_dist_sender_host_logic(world, G, split):
         p.join(180)
         assert p.exitcode == 0
     assert sorted(out.get(timeout=5)[0] for _ in range(world)) == list(range(world))
+
+
+# ---- the mat-vec form of the resident databases: agreed by every rank, re-agreed when ANY rank's database changed
+class FormContext(FakeContext):
+    """FakeContext + what DistDiagonalSender reads the form off: db_kind / db_babies (0 = nothing enrolled) and the policy"""
+    kind, babies = 0, 0
+
+    def db_kind(self):
+        return self.kind
+
+    def db_babies(self):
+        return self.babies
+
+    def auto_babies(self, blocks):
+        return self.dim
+
+
+def _form_worker(rank, world, port, case, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cc = FormContext()
+    query = np.random.default_rng(5).integers(0, Q[0], size=(1, 2, NQ, N), dtype=np.uint64)
+    G = 2
+    lo, hi = sharding.shard_blocks(G, world, rank)
+    holds = hi > lo
+    # (a) the sender is built BEFORE anything is enrolled
+    sender = sharding.DistDiagonalSender(cc, G * SLOTS, dist, rank, world, staging="host",
+                                         make_sender=lambda c, n: FakeSender(lo, hi, query), rotation_split=True)
+    assert sender._form in (None, (0, 0))
+    q = FakeCt(query, 2.0 ** 45) if rank == 0 else None
+    want = np.stack([block_result(g, 2) for g in range(G)])
+    if holds:
+        cc.kind, cc.babies = 5, cc.dim  # hoisted
+    idx = sender.indexScenario(q)  # first call: every rank re-agrees (the block-less rank learns of it through the reduce)
+    assert (idx is None) == (rank != 0) and (rank != 0 or np.array_equal(idx.export(), want))
+    assert not sender.bsgs and sender.babies == cc.dim and sender.rotation_split == (len(sender.active) > 1)
+    verdict = "ok"
+    if case == "reenrol":  # (b) every block-holding rank re-enrols pre-rotated: the next call switches form by itself
+        if holds:
+            cc.kind, cc.babies = 6, 2
+        idx = sender.indexScenario(q)
+        assert (rank != 0 or np.array_equal(idx.export(), want)) and sender.bsgs and sender.babies == 2 and not sender.rotation_split
+        if holds:
+            cc.kind, cc.babies = 5, cc.dim
+        sender.refresh_form()  # ... and the explicit form of the same
+        assert not sender.bsgs and sender.rotation_split == (len(sender.active) > 1)
+        idx = sender.indexScenario(q)
+        assert rank != 0 or np.array_equal(idx.export(), want)
+    elif case == "disagree":  # (c) more ranks than blocks, the two block-holding ranks end up with different forms: a clean error on EVERY rank
+        if rank == 0:
+            cc.kind, cc.babies = 6, 2
+        try:
+            sender.indexScenario(q)
+            verdict = "no error"
+        except ValueError as e:
+            verdict = "ValueError" if "different mat-vec forms" in str(e) else "other: %s" % e
+    out.put((rank, verdict))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "reenrol"), (3, "reenrol"), (3, "disagree")])
+def test_dist_sender_form_changes_are_rank_symmetric(world, case):
+    """a sender built before enrolment works at its first call; a re-enrolment in another form is picked up by every rank (world 3: the
+    third rank holds no block and cannot see the change itself); disagreeing forms raise on every rank instead of hanging the others"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_form_worker, args=(r, world, port, case, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "a rank hung or failed"
+    got = dict(out.get(timeout=5) for _ in range(world))
+    assert got == {r: ("ValueError" if case == "disagree" else "ok") for r in range(world)}

@@ -1,0 +1,310 @@
+// tools/ubench/p2_swap.hip — round 5, VERDICT item 1(a): how should the lanes of NTT pass 2 exchange values?
+//
+// Pass 2 of the N = 2^15 forward transform (stages 7-14 inside 256-coefficient blocks; image_matching_amd/csrc/ntt15.hip p2_body)
+// runs three register phases (stages 7-9, 10-12, 13-14) with two exchanges between them.  Three forms of the SAME butterflies on the
+// same operands (outputs compared bit for bit):
+//   wg-lds     round 4: LDS exchanges behind s_barrier, phase C takes coefficients 4t + 1024 hh of the workgroup's 2048-chunk
+//   wave-lds   a block belongs to one half-wave in every phase: the LDS exchanges stay, the barriers go (the LDS executes one wave's
+//              instructions in order)
+//   wave-swap  no LDS at all: a (register bit <-> lane bit) exchange is a HALF swap between partner lanes — v_permlane16_swap for lane
+//              distance 16, v_cndmask_b32_dpp (row_ror:8, row_shl/shr:4, quad_perm) for 8, 4, 2, 1 — two dword moves per 64-bit value
+// for the two arithmetics of the production chain (FpA: 45-bit primes on the FP64 pipe; IntP: 2^60 - c lazy integers), NP = 2
+// polynomials per workgroup, in two regimes: "L2" (a working set of 16 MiB re-transformed 64 times: everything but HBM) and
+// "HBM" (1536 limb-polynomials = 384 MiB in, 384 MiB out per launch).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I image_matching_amd/csrc -o tools/ubench/p2_swap tools/ubench/p2_swap.hip
+#include "kernels.h"
+#include "ntt_arith.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+namespace {
+
+constexpr int ROW = 36, IMG = 8 * 288;  // the padded LDS image of ntt15.hip (P2Lds<false>)
+DEV int at(int blk, int row, int pos) { return blk * 288 + row * ROW + pos; }
+
+DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- half swaps: A is the register the lanes with the lane bit CLEAR keep, B the one the lanes with the bit SET keep.
+// Afterwards a clear lane holds (own A, partner's A) and a set lane (partner's B, own B): register bit and lane bit have changed places.
+DEV void split(u64 x, unsigned &l, unsigned &h) { l = (unsigned)x; h = (unsigned)(x >> 32); }
+DEV u64 join(unsigned l, unsigned h) { return (u64)l | ((u64)h << 32); }
+template <class T> DEV u64 bits(T x);
+template <> DEV u64 bits<u64>(u64 x) { return x; }
+template <> DEV u64 bits<double>(double x) { return (u64)__double_as_longlong(x); }
+template <class T> DEV T unbits(u64 x);
+template <> DEV u64 unbits<u64>(u64 x) { return x; }
+template <> DEV double unbits<double>(u64 x) { return __longlong_as_double((long long)x); }
+
+template <class T>
+DEV void swap16(T &A, T &B) {
+    unsigned al, ah, bl, bh;
+    split(bits(A), al, ah);
+    split(bits(B), bl, bh);
+    auto r0 = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    A = unbits<T>(join(r0[0], r1[0]));
+    B = unbits<T>(join(r0[1], r1[1]));
+}
+#define DPP_TAIL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// two 64-bit pairs per statement: eight v_cndmask_b32_dpp, the mask in vcc (VOP2) flipped once; s_nop 1 = the two wait states between a
+// vector write of an operand and a DPP read of it (the hazard recogniser does not look inside the string)
+#define SWAP_DPP2(NAME, CC, CS)                                                                                                  \
+    template <class T>                                                                                                           \
+    DEV void NAME(T &A0, T &B0, T &A1, T &B1, u64 setm) {                                                                        \
+        unsigned a0l, a0h, b0l, b0h, a1l, a1h, b1l, b1h, na0l, na0h, nb0l, nb0h, na1l, na1h, nb1l, nb1h;                        \
+        split(bits(A0), a0l, a0h); split(bits(B0), b0l, b0h); split(bits(A1), a1l, a1h); split(bits(B1), b1l, b1h);              \
+        asm("s_nop 1\n\ts_mov_b64 vcc, %16\n\t"                                                                                   \
+            "v_cndmask_b32_dpp %4, %8, %10, vcc " CC DPP_TAIL "v_cndmask_b32_dpp %5, %9, %11, vcc " CC DPP_TAIL                   \
+            "v_cndmask_b32_dpp %6, %12, %14, vcc " CC DPP_TAIL "v_cndmask_b32_dpp %7, %13, %15, vcc " CC DPP_TAIL                 \
+            "s_not_b64 vcc, vcc\n\t"                                                                                              \
+            "v_cndmask_b32_dpp %0, %10, %8, vcc " CS DPP_TAIL "v_cndmask_b32_dpp %1, %11, %9, vcc " CS DPP_TAIL                   \
+            "v_cndmask_b32_dpp %2, %14, %12, vcc " CS DPP_TAIL "v_cndmask_b32_dpp %3, %15, %13, vcc " CS DPP_TAIL                 \
+            : "=&v"(na0l), "=&v"(na0h), "=&v"(na1l), "=&v"(na1h), "=&v"(nb0l), "=&v"(nb0h), "=&v"(nb1l), "=&v"(nb1h)              \
+            : "v"(a0l), "v"(a0h), "v"(b0l), "v"(b0h), "v"(a1l), "v"(a1h), "v"(b1l), "v"(b1h), "s"(setm)                           \
+            : "vcc", "scc");                                                                                                      \
+        A0 = unbits<T>(join(na0l, na0h)); B0 = unbits<T>(join(nb0l, nb0h));                                                       \
+        A1 = unbits<T>(join(na1l, na1h)); B1 = unbits<T>(join(nb1l, nb1h));                                                       \
+    }
+SWAP_DPP2(swap8, "row_ror:8", "row_ror:8")
+SWAP_DPP2(swap4, "row_shl:4", "row_shr:4")
+SWAP_DPP2(swap2, "quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]")
+SWAP_DPP2(swap1, "quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]")
+
+// ---- the three register phases (ntt15.hip p2_body, forward, plain store)
+template <class A>
+DEV void phase_a(const A &ar, const ulonglong2 *__restrict__ tw, typename A::T (&v)[8], int bg) {
+    typedef typename A::TW TW;
+    const TW W7 = A::tw(tw[128 + bg]);
+    const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
+    TW W9[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ar.ct(v[k], v[k + 4], W7);
+    ar.ct(v[0], v[2], W8a);
+    ar.ct(v[1], v[3], W8a);
+    ar.ct(v[4], v[6], W8b);
+    ar.ct(v[5], v[7], W8b);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) ar.ct(v[k], v[k + 1], W9[k >> 1]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ar.fwd_fold(v[k]);
+}
+template <class A>
+struct TwB {
+    typename A::TW W10, W11a, W11b, W12[4];
+    DEV void load(const ulonglong2 *__restrict__ tw, int ib) {
+        W10 = A::tw(tw[1024 + ib]);
+        W11a = A::tw(tw[2048 + 2 * ib]);
+        W11b = A::tw(tw[2048 + 2 * ib + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
+    }
+};
+template <class A>
+DEV void phase_b(const A &ar, const TwB<A> &W, typename A::T (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) ar.ct(v[k], v[k + 4], W.W10);
+    ar.ct(v[0], v[2], W.W11a);
+    ar.ct(v[1], v[3], W.W11a);
+    ar.ct(v[4], v[6], W.W11b);
+    ar.ct(v[5], v[7], W.W11b);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) ar.ct(v[k], v[k + 1], W.W12[k >> 1]);
+}
+// four consecutive coefficients e .. e+3 of the chunk at d (global index B0 + e)
+template <class A>
+DEV void phase_c(const A &ar, const ulonglong2 *__restrict__ tw, typename A::T c0, typename A::T c1, typename A::T c2, typename A::T c3,
+                 int gidx, u64 *d) {
+    typedef typename A::TW TW;
+    const int gi = gidx >> 2;
+    const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
+    ar.mid(c0); ar.mid(c1); ar.mid(c2); ar.mid(c3);
+    ar.ct(c0, c2, W13);
+    ar.ct(c1, c3, W13);
+    ar.ct(c0, c1, W14a);
+    ar.ct(c2, c3, W14b);
+    *reinterpret_cast<ulonglong2 *>(d) = make_ulonglong2(ar.fin_fwd(c0), ar.fin_fwd(c1));
+    *reinterpret_cast<ulonglong2 *>(d + 2) = make_ulonglong2(ar.fin_fwd(c2), ar.fin_fwd(c3));
+}
+
+// VAR 0 wg-lds, 1 wave-lds, 2 wave-swap.  grid (16 chunks, polys / 2), 256 threads; REPS passes over the same chunk pair.
+template <class A, int VAR>
+__global__ __launch_bounds__(256) void k_p2(const ulonglong2 *__restrict__ tw, ModC M, const u64 *__restrict__ src, u64 *__restrict__ dst, int reps) {
+    constexpr int NP = 2, N = 32768;
+    typedef typename A::T T;
+    __shared__ u64 lds[VAR == 2 ? 1 : NP][VAR == 2 ? 1 : IMG];
+    const A ar(M);
+    const int t = threadIdx.x, blk = t >> 5, w = t & 31, B0 = blockIdx.x * 2048, bg = (B0 >> 8) + blk;
+    const int a = w >> 2, b = w & 3;
+    const u64 setm4 = 0xF0F0F0F0F0F0F0F0ull, setm8 = 0xFF00FF00FF00FF00ull, setm2 = 0xCCCCCCCCCCCCCCCCull, setm1 = 0xAAAAAAAAAAAAAAAAull;
+    for (int rep = 0; rep < reps; rep++) {
+        const u64 *s[NP];
+        u64 *d[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            s[p] = src + (size_t)(blockIdx.y * NP + p) * N + B0;
+            d[p] = dst + (size_t)(blockIdx.y * NP + p) * N + B0;
+        }
+        T v[NP][8];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[p][k] = ar.from_raw(s[p][blk * 256 + 32 * k + w]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) phase_a(ar, tw, v[p], bg);
+        TwB<A> WB;
+        WB.load(tw, 8 * bg + a);
+        if (VAR == 2) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                // registers (j7, j6, j5) <-> lanes (j4, j3, j2)
+#pragma unroll
+                for (int k = 0; k < 4; k++) swap16(v[p][k], v[p][k + 4]);
+                swap8(v[p][0], v[p][2], v[p][1], v[p][3], setm8);
+                swap8(v[p][4], v[p][6], v[p][5], v[p][7], setm8);
+                swap4(v[p][0], v[p][1], v[p][2], v[p][3], setm4);
+                swap4(v[p][4], v[p][5], v[p][6], v[p][7], setm4);
+                phase_b(ar, WB, v[p]);
+                // registers (j3, j2) <-> lanes (j1, j0): afterwards v[4 hh + 0..3] are four consecutive coefficients
+                swap2(v[p][0], v[p][2], v[p][1], v[p][3], setm2);
+                swap2(v[p][4], v[p][6], v[p][5], v[p][7], setm2);
+                swap1(v[p][0], v[p][1], v[p][2], v[p][3], setm1);
+                swap1(v[p][4], v[p][5], v[p][6], v[p][7], setm1);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int e = blk * 256 + a * 32 + 16 * hh + 4 * b;
+#pragma unroll
+                for (int p = 0; p < NP; p++) phase_c(ar, tw, v[p][4 * hh], v[p][4 * hh + 1], v[p][4 * hh + 2], v[p][4 * hh + 3], B0 + e, d[p] + e);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) lds[p][at(blk, k, w)] = A::to_bits(v[p][k]);
+            if (VAR == 0) __syncthreads();
+            else wave_sync();
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][at(blk, a, 4 * k + b)]);
+                phase_b(ar, WB, v[p]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) lds[p][at(blk, a, 4 * k + b)] = A::to_bits(v[p][k]);
+            }
+            if (VAR == 0) __syncthreads();
+            else wave_sync();
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int e = VAR == 0 ? 4 * t + 1024 * hh : blk * 256 + 4 * w + 128 * hh;
+                const int u = e & 255, la = at(e >> 8, u >> 5, u & 31);
+#pragma unroll
+                for (int p = 0; p < NP; p++)
+                    phase_c(ar, tw, A::from_bits(lds[p][la]), A::from_bits(lds[p][la + 1]), A::from_bits(lds[p][la + 2]), A::from_bits(lds[p][la + 3]),
+                            B0 + e, d[p] + e);
+            }
+            if (reps > 1) {  // the next repetition overwrites the image
+                if (VAR == 0) __syncthreads();
+                else wave_sync();
+            }
+        }
+    }
+}
+
+u64 mulmod_h(u64 a, u64 b, u64 q) { return (u64)((u128)a * b % q); }
+
+}  // namespace
+
+template <class A, int VAR>
+static float run(const ulonglong2 *tw, const ModC &M, const u64 *src, u64 *dst, int polys, int reps, int launches) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_p2<A, VAR>), dim3(16, polys / 2), dim3(256), 0, 0, tw, M, src, dst, reps);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < launches; i++) hipLaunchKernelGGL((k_p2<A, VAR>), dim3(16, polys / 2), dim3(256), 0, 0, tw, M, src, dst, reps);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms / launches;
+}
+
+int main() {
+    constexpr int N = 32768;
+    const int polys_hbm = 1536, polys_l2 = 64;
+    const u64 q_fp = (1ull << 45) + 65537 * 0 + 589825;  // any odd 45-bit modulus serves the timing (the butterflies branch on nothing)
+    const u64 q_int = (1ull << 60) - 1114111;          // 2^60 - c, c < 2^24
+    std::mt19937_64 rng(5);
+    // twiddle tables of random residues: pairs (w, floor(w 2^64 / q)) and (double w, double w / q)
+    std::vector<u64> twp(2 * N), twf(2 * N);
+    for (int k = 0; k < N; k++) {
+        const u64 wi = rng() % q_int, wf = rng() % q_fp;
+        twp[2 * k] = wi;
+        twp[2 * k + 1] = (u64)((((u128)wi) << 64) / q_int);
+        const double dw = (double)wf, dq = dw / (double)q_fp;
+        memcpy(&twf[2 * k], &dw, 8);
+        memcpy(&twf[2 * k + 1], &dq, 8);
+    }
+    ulonglong2 *d_twp, *d_twf;
+    CK(hipMalloc((void **)&d_twp, 16 * N));
+    CK(hipMalloc((void **)&d_twf, 16 * N));
+    CK(hipMemcpy(d_twp, twp.data(), 16 * N, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_twf, twf.data(), 16 * N, hipMemcpyHostToDevice));
+    ModC Mi{}, Mf{};
+    Mi.q = q_int;
+    Mf.q = q_fp;
+    const size_t n = (size_t)polys_hbm * N;
+    u64 *d_src, *d_dst;
+    CK(hipMalloc((void **)&d_src, n * 8));
+    CK(hipMalloc((void **)&d_dst, n * 8));
+    std::vector<u64> h(n), ref((size_t)polys_l2 * N), out((size_t)polys_l2 * N);
+    const char *names[3] = {"wg-lds   (round 4)", "wave-lds (no barrier)", "wave-swap (no LDS)"};
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const double clk = prop.clockRate * 1e3, cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, %.0f MHz\n", prop.name, prop.multiProcessorCount, clk / 1e6);
+    for (int arith = 0; arith < 2; arith++) {
+        // pass-1 output as pass 2 reads it: raw doubles of small integers (FpA) / lazy 64-bit values (IntP)
+        for (size_t i = 0; i < n; i++) {
+            if (arith == 0) {
+                const double x = (double)(long long)(rng() % q_fp);
+                memcpy(&h[i], &x, 8);
+            } else h[i] = rng();
+        }
+        CK(hipMemcpy(d_src, h.data(), n * 8, hipMemcpyHostToDevice));
+        printf("%s\n", arith == 0 ? "FpA (45-bit prime, FP64 butterflies)" : "IntP (2^60 - c, lazy integer butterflies)");
+        for (int var = 0; var < 3; var++) {
+            CK(hipMemset(d_dst, 0, n * 8));
+            float l2 = 0, hbm = 0;
+            const ulonglong2 *tw = arith == 0 ? d_twf : d_twp;
+            const ModC &M = arith == 0 ? Mf : Mi;
+#define RUN(AR, V) { l2 = run<AR, V>(tw, M, d_src, d_dst, polys_l2, 64, 5); hbm = run<AR, V>(tw, M, d_src, d_dst, polys_hbm, 1, 10); }
+            if (arith == 0) { if (var == 0) RUN(FpA, 0) else if (var == 1) RUN(FpA, 1) else RUN(FpA, 2) }
+            else { if (var == 0) RUN(IntP, 0) else if (var == 1) RUN(IntP, 1) else RUN(IntP, 2) }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(out.data(), d_dst, out.size() * 8, hipMemcpyDeviceToHost));
+            if (var == 0) ref = out;
+            size_t bad = 0;
+            for (size_t i = 0; i < out.size(); i++) bad += out[i] != ref[i];
+            const double coef_l2 = (double)polys_l2 * N * 64, coef_hbm = (double)polys_hbm * N;
+            printf("  %-22s L2-resident: %7.3f ms = %6.3f ns per 2048-chunk pair, %5.2f CU-cycles per coefficient | HBM stream: %7.3f ms = %5.2f TB/s | %s\n",
+                   names[var], l2, l2 * 1e6 / (polys_l2 / 2 * 16 * 64.0), l2 * 1e-3 * clk * cus / coef_l2, hbm, coef_hbm * 16 / (hbm * 1e-3) / 1e12,
+                   bad ? "MISMATCH" : "bit-identical");
+            if (bad) printf("    %zu of %zu outputs differ from wg-lds\n", bad, out.size());
+        }
+    }
+    (void)mulmod_h;
+    return 0;
+}
