@@ -301,6 +301,8 @@ def launcher_selftest(world, rank):
         print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_initialised": dist.get_world_size(),
                           "backend": dist.get_backend(), "rank_sum": float(t.item()),
                           "self_launched": os.environ.get("HYDIA_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    if os.environ.get("HYDIA_BENCH_SELFTEST_HANG_RANK") == str(rank) and rank != 0:
+        time.sleep(3600)  # (test of the launcher's straggler deadline)
     dist.destroy_process_group()
 
 

@@ -4,6 +4,7 @@
 // every ModUp and ModDown: the hoisted rotations of DiagonalSender::computeSimilarity (/root/reference/src/sender/sender_diag.cpp:22-26),
 // RelinearizeInPlace + RescaleInPlace (:79-80) and the ct x ct products of chebyshevCompare (src/openFHE_wrapper.cpp:143-185).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "ntt_arith.h"
@@ -176,11 +177,11 @@ DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 // last digit) hold zeros, so the sum is branch-free: four lazy 128-bit multiply-accumulates.
 // Integer targets (the 60-bit limb 0): canonical residue, single-word Barrett on the top bits (reduce128k: at most four products of
 // residues below 2^60 with constants below q).
-template <class A, bool MDR>
-DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
-                    unsigned neg, typename A::T (&v)[16], bool nosrc) {
+template <class A, bool MDR, int NR>
+DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][NR], const u64 *um /* [k * 256] */,
+                    unsigned neg, typename A::T (&v)[NR], bool nosrc) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < NR; k++) {
         u64 r = nosrc ? 0 : reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f).wide(), M);
         if (MDR) {
             const u64 c = reduce64(um[k * 256], M);
@@ -192,11 +193,11 @@ DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[
 // Pseudo-Mersenne targets (q_0 and the special primes, 2^60 - c): the two-word sum is FOLDED (IntP::fold_lh, four multiply-adds) to a
 // lazy representative below 2.07 2^60 instead of Barrett-reduced — with the dropped limb's residue (at most q) the forward
 // butterflies start below 3.1 q and reach 15.1 q at their first fold (bound 16 q).
-template <bool MDR>
-DEV void cf_convert(const IntP ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
-                    unsigned neg, u64 (&v)[16], bool nosrc) {
+template <bool MDR, int NR>
+DEV void cf_convert(const IntP ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][NR], const u64 *um /* [k * 256] */,
+                    unsigned neg, u64 (&v)[NR], bool nosrc) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < NR; k++) {
         u64 r = 0;
         if (!nosrc) {
             const CfSum a = cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f);
@@ -209,11 +210,11 @@ DEV void cf_convert(const IntP ar, const ModC &M, const CfConst &f, const u64 (&
         v[k] = r;
     }
 }
-template <bool MDR>
-DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][16], const u64 *um /* [k * 256] */,
-                    unsigned neg, double c60, double (&v)[16], bool nosrc) {
+template <bool MDR, int NR>
+DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][NR], const u64 *um /* [k * 256] */,
+                    unsigned neg, double c60, double (&v)[NR], bool nosrc) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < NR; k++) {
         double r = nosrc ? 0.0 : cf_fold(ar, cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f), c60);
         if (MDR) {
             const double c = FpA::u2d(um[k * 256]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
@@ -344,21 +345,267 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
         if (fp) {
             const FpA ar(M);
             double v[16];
-            cf_convert<MDR>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v, MDR && cf.nk == 0);
+            cf_convert<MDR, 16>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v, MDR && cf.nk == 0);
             CF_STORE_LTW();
             cf_forward<FpA>(ar, tw, ltw, lds, g, col, v, d);
         } else if ((T.pm_mask >> m) & 1u) {
             const IntP ar(M);
             u64 v[16];
-            cf_convert<MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            cf_convert<MDR, 16>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
             CF_STORE_LTW();
             cf_forward<IntP>(ar, tw, ltw, lds, g, col, v, d);
         } else {
             const IntA ar(M);
             u64 v[16];
-            cf_convert<IntA, MDR>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            cf_convert<IntA, MDR, 16>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
             CF_STORE_LTW();
             cf_forward<IntA>(ar, tw, ltw, lds, g, col, v, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the narrow form (round 5)
+// The kernel above keeps 4 sources x 16 rows per lane (128 registers) and two 32 KiB images: 236-256 registers and 78 KiB of LDS, TWO
+// workgroups per CU and nothing else beside them — no third wave (r04: 82 % / 74 % of the issue slots at two waves), and no workgroup of
+// ANOTHER kernel on the CU either, which is why the per-block tails' two streams never overlapped a vector-bound conversion with a
+// memory-bound transform.  Here a workgroup owns 16 columns and a lane 8 rows of each source (64 registers): the 128-point column
+// transform becomes 3 + 3 + 1 stages with TWO exchanges (rows g + 16k -> 16h + 2l + e -> 8g + m; g = t >> 4, h = g >> 1, e = g & 1)
+// through 16 KiB images — same butterflies on the same operands, same folds: bit-identical — at <= 168 registers and 46 KiB of LDS:
+// three workgroups per CU, or two beside other kernels' workgroups.  HYDIA_COLFUSE_WIDE=1 runs the kernel above.
+constexpr int CF8_COLS = 16, CF8_IMG = 128 * CF8_COLS;
+constexpr int CF8_LDS_BYTES = 2 * CF8_IMG * 8 + (HY_CF_SRC + 1 + 2) * 128 * 16;
+
+// y: in = raw pass-2' values of rows 8g + m at index m; out = canonical coefficient-form residues (times sc) of rows g + 16k at index k
+template <class A>
+DEV void cf_inverse8(const A ar, const ulonglong2 *__restrict__ tw, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs,
+                     u64 (&y)[8]) {
+    typedef typename A::T T;
+    T w[8];
+    // phase C': stage 6 (row bit 0)
+#pragma unroll
+    for (int m = 0; m < 8; m++) w[m] = A::from_bits(y[m]);
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) ar.gs(w[m], w[m + 1], A::tw(ltw[64 + 4 * g + (m >> 1)]));
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        ar.recentre(w[m]);
+        lds[(8 * g + m) * CF8_COLS + col] = A::to_bits(w[m]);
+    }
+    __syncthreads();
+    // phase B': rows 16h + 2l + e, stages 5, 4, 3 (row bits 1, 2, 3); written back in place (a lane's own slots)
+    const int h = g >> 1, e = g & 1;
+#pragma unroll
+    for (int l = 0; l < 8; l++) w[l] = A::from_bits(lds[(16 * h + 2 * l + e) * CF8_COLS + col]);
+#pragma unroll
+    for (int l = 0; l < 8; l += 2) ar.gs(w[l], w[l + 1], A::tw(ltw[32 + 4 * h + (l >> 1)]));
+#pragma unroll
+    for (int l = 0; l < 8; l++)
+        if (!(l & 2)) ar.gs(w[l], w[l + 2], A::tw(ltw[16 + 2 * h + (l >> 2)]));
+    {
+        const typename A::TW W = A::tw(ltw[8 + h]);
+#pragma unroll
+        for (int l = 0; l < 4; l++) ar.gs(w[l], w[l + 4], W);
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        ar.recentre(w[l]);
+        lds[(16 * h + 2 * l + e) * CF8_COLS + col] = A::to_bits(w[l]);
+    }
+    __syncthreads();
+    // phase A': rows g + 16k, stages 2, 1, 0 (row bits 4, 5, 6): workgroup-uniform twiddles
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = A::from_bits(lds[(g + 16 * k) * CF8_COLS + col]);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) ar.gs(w[k], w[k + 1], A::tw(tw[4 + (k >> 1)]));
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (!(k & 2)) ar.gs(w[k], w[k + 2], A::tw(tw[2 + (k >> 2)]));
+    {
+        const typename A::TW W = A::tw(tw[1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) ar.gs(w[k], w[k + 4], W);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) y[k] = ar.fin_inv(w[k], sc, scs);
+}
+DEV void cf_inverse8_any(const NttTables &T, int m, const ModC &M, const ulonglong2 *ltw, u64 *lds, int g, int col, u64 sc, u64 scs,
+                         u64 (&y)[8], bool split) {
+    const bool fp = (T.fp_mask >> m) & 1u;
+    const ulonglong2 *__restrict__ tw = (fp ? T.itwf : T.itwp) + (size_t)m * 32768;
+    if (fp) cf_inverse8<FpA>(FpA(M), tw, ltw, lds, g, col, sc, scs, y);
+    else if ((T.pm_mask >> m) & 1u) cf_inverse8<IntP>(IntP(M), tw, ltw, lds, g, col, sc, scs, y);
+    else cf_inverse8<IntA>(IntA(M), tw, ltw, lds, g, col, sc, scs, y);
+    if (split) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = cf_split30(y[k]);
+    }
+}
+// v: operands of rows g + 16k; the raw pass-1 image (rows 8g + m of the lane's column) leaves through d
+template <class A>
+DEV void cf_forward8(const A ar, const ulonglong2 *__restrict__ tw, const ulonglong2 *ltw, u64 *lds, int g, int col, typename A::T (&v)[8], u64 *d) {
+    typedef typename A::T T;
+    // phase A: stages 0, 1, 2
+    {
+        const typename A::TW W = A::tw(tw[1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) ar.ct(v[k], v[k + 4], W);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (!(k & 2)) ar.ct(v[k], v[k + 2], A::tw(tw[2 + (k >> 2)]));
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) ar.ct(v[k], v[k + 1], A::tw(tw[4 + (k >> 1)]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        ar.fwd_fold(v[k]);  // lazy 60-bit limbs: three stages between folds (ntt_arith.h)
+        lds[(g + 16 * k) * CF8_COLS + col] = A::to_bits(v[k]);
+    }
+    __syncthreads();
+    // phase B: rows 16h + 2l + e, stages 3, 4, 5
+    const int h = g >> 1, e = g & 1;
+    T w[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) w[l] = A::from_bits(lds[(16 * h + 2 * l + e) * CF8_COLS + col]);
+    {
+        const typename A::TW W = A::tw(ltw[8 + h]);
+#pragma unroll
+        for (int l = 0; l < 4; l++) ar.ct(w[l], w[l + 4], W);
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++)
+        if (!(l & 2)) ar.ct(w[l], w[l + 2], A::tw(ltw[16 + 2 * h + (l >> 2)]));
+#pragma unroll
+    for (int l = 0; l < 8; l += 2) ar.ct(w[l], w[l + 1], A::tw(ltw[32 + 4 * h + (l >> 1)]));
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        ar.fwd_fold(w[l]);
+        lds[(16 * h + 2 * l + e) * CF8_COLS + col] = A::to_bits(w[l]);
+    }
+    __syncthreads();
+    // phase C: rows 8g + m, stage 6
+#pragma unroll
+    for (int m = 0; m < 8; m++) w[m] = A::from_bits(lds[(8 * g + m) * CF8_COLS + col]);
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) ar.ct(w[m], w[m + 1], A::tw(ltw[64 + 4 * g + (m >> 1)]));
+#pragma unroll
+    for (int m = 0; m < 8; m++) d[(size_t)(8 * g + m) * 256 + col] = A::to_bits(w[m]);  // raw: pass 2 finishes
+}
+
+// grid (16 column tiles, XP polynomials, ncf maps x target slices), 256 threads: col = t & 15, g = t >> 4
+template <bool MDR>
+__global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
+                                                            size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz) {
+    constexpr int N = 32768;
+    extern __shared__ __attribute__((aligned(16))) u64 cf_smem[];
+    u64 *const img = cf_smem;  // two exchange images of 128 x 16
+    ulonglong2 *const sltw = reinterpret_cast<ulonglong2 *>(cf_smem + 2 * CF8_IMG);  // [HY_CF_SRC + 1][128]
+    ulonglong2 *const tltw = sltw + (HY_CF_SRC + 1) * 128;                          // [2][128]
+    const int zi = blockIdx.z / slices, zs = blockIdx.z - zi * slices;
+    const ColFuse &cf = cfs[zi];
+    const int t_lo = zs * tz, t_hi = min(cf.nt, t_lo + tz);
+    if (t_lo >= t_hi) return;  // workgroup-uniform
+    const int t = threadIdx.x, col = t & (CF8_COLS - 1), g = t >> 4;
+    const int xp = blockIdx.y, c0 = blockIdx.x * CF8_COLS;
+    const u64 *sb = src + (size_t)xp * so + c0 + col;
+    // ---- every global load of the workgroup, up front: the raw pass-2' values of rows 8g + m, where pass 1' starts
+    u64 *const umem = cf_smem + CF8_IMG + t;  // MDR: lane t's slot of row k at umem[k * 256] (the second image)
+    u64 y[HY_CF_SRC][8], um[8];
+    if (MDR) {
+        const u64 *sp = sb + (size_t)cf.urow * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) um[m] = sp[(size_t)(8 * g + m) * 256];
+    }
+#pragma unroll
+    for (int s = 0; s < HY_CF_SRC; s++) {
+        if (s >= cf.nk) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) y[s][k] = 0;
+        } else {
+            const u64 *sp = sb + (size_t)cf.srow[s] * N;
+#pragma unroll
+            for (int m = 0; m < 8; m++) y[s][m] = sp[(size_t)(8 * g + m) * 256];
+        }
+    }
+    if (t < 128) {
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++)
+            if (s < cf.nk) {
+                const int m = cf.smod[s];
+                const bool fp = (T.fp_mask >> m) & 1u;
+                sltw[s * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
+            }
+        if (MDR) {
+            const int m = cf.umod;
+            const bool fp = (T.fp_mask >> m) & 1u;
+            sltw[HY_CF_SRC * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
+        }
+    }
+    __syncthreads();
+    int buf = 0;
+    // MDR exchanges through image 0 only (image 1 holds the dropped limb's residues): a barrier before an image is rewritten
+#define CF8_NEXT_IMAGE() (MDR ? (__syncthreads(), img) : img + (buf ^= 1) * CF8_IMG)
+    if (MDR) {
+        cf_inverse8_any(T, cf.umod, cf.uM, sltw + HY_CF_SRC * 128, CF8_NEXT_IMAGE(), g, col, cf.usc, cf.usc_sh, um, false);
+#pragma unroll
+        for (int k = 0; k < 8; k++) umem[k * 256] = um[k];
+    }
+    if (0 < cf.nk) cf_inverse8_any(T, cf.smod[0], cf.sM[0], sltw, CF8_NEXT_IMAGE(), g, col, cf.ssc[0], cf.ssc_sh[0], y[0], true);
+    if (1 < cf.nk) cf_inverse8_any(T, cf.smod[1], cf.sM[1], sltw + 128, CF8_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], true);
+    if (2 < cf.nk) cf_inverse8_any(T, cf.smod[2], cf.sM[2], sltw + 256, CF8_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], true);
+    if (3 < cf.nk) cf_inverse8_any(T, cf.smod[3], cf.sM[3], sltw + 384, CF8_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], true);
+    // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
+    unsigned neg = 0;
+    if (MDR) {
+        const ModC Ml = cf.lM;
+        const u64 half = Ml.q >> 1;
+        CfConst fl;
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) fl.set(s, s < cf.nk ? cf.fl[s] : 0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u64 yl = cf.nk == 0 ? umem[k * 256]  // a plain Rescale: the dropped limb itself
+                                      : submod(umem[k * 256], reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], fl).wide(), Ml), Ml.q);  // own slot: no barrier needed
+            const bool ng = yl > half;
+            umem[k * 256] = ng ? Ml.q - yl : yl;
+            neg |= (ng ? 1u : 0u) << k;
+        }
+    }
+    // ---- every target of this slice: conversion, pass 1, raw image out (see the wide kernel for the vmcnt / twiddle-store remarks)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    for (int tt = t_lo; tt < t_hi; tt++) {
+        const int m = cf.tmod[tt];
+        const ModC M = cf.tM[tt];
+        const bool fp = (T.fp_mask >> m) & 1u;
+        const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
+        ulonglong2 *ltw = tltw + (tt & 1) * 128;
+        u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;  // cf_forward8 adds the lane's column
+        u64 *lds = CF8_NEXT_IMAGE();
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) asm volatile("" : "+v"(y[s][k]));
+        CfConst f;
+#pragma unroll
+        for (int s = 0; s < HY_CF_SRC; s++) f.set(s, s < cf.nk ? cf.f[s][tt] : 0);
+        const ulonglong2 ltv = tw[t & 127];
+        if (fp) {
+            const FpA ar(M);
+            double v[8];
+            cf_convert<MDR, 8>(ar, M, f, y, umem, neg, FpA::u2d(cf.t60[tt]), v, MDR && cf.nk == 0);
+            ltw[t & 127] = ltv;
+            cf_forward8<FpA>(ar, tw, ltw, lds, g, col, v, d);
+        } else if ((T.pm_mask >> m) & 1u) {
+            const IntP ar(M);
+            u64 v[8];
+            cf_convert<MDR, 8>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            ltw[t & 127] = ltv;
+            cf_forward8<IntP>(ar, tw, ltw, lds, g, col, v, d);
+        } else {
+            const IntA ar(M);
+            u64 v[8];
+            cf_convert<IntA, MDR, 8>(ar, M, f, y, umem, neg, v, MDR && cf.nk == 0);
+            ltw[t & 127] = ltv;
+            cf_forward8<IntA>(ar, tw, ltw, lds, g, col, v, d);
         }
     }
 }
@@ -459,7 +706,15 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
 
 namespace hk {
 
-bool ntt15_colfuse_small(int XP, int ncf) { return 8 * XP * ncf < 256; }
+// launches below this many 32-column tiles take the small-launch form (pass 1' as its own launch + one target per workgroup).
+// HYDIA_CF_SMALL=<tiles> moves the crossover (0: never) — an experiment knob, read once per process
+bool ntt15_colfuse_small(int XP, int ncf) {
+    static const int lim = [] {
+        const char *e = getenv("HYDIA_CF_SMALL");
+        return e ? atoi(e) : 256;
+    }();
+    return 8 * XP * ncf < lim;
+}
 
 void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
                    const ColFuse *h_cf, int ncf, bool pre) {
@@ -482,6 +737,17 @@ void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so
         ledger_add(mdr ? "k_ntt15_conv_p1<true>" : "k_ntt15_conv_p1<false>", rows * XP * 262144.0);
         if (mdr) hipLaunchKernelGGL((k_ntt15_conv_p1<true>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
         else hipLaunchKernelGGL((k_ntt15_conv_p1<false>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
+        return;
+    }
+    if (!T.cf_wide) {  // the narrow form: 16 column tiles of 16 columns
+        ledger_add(mdr ? "k_ntt15_colfuse8<true>" : "k_ntt15_colfuse8<false>", rows * XP * 262144.0);
+        const int base8 = 16 * XP * ncf;
+        int sl = 1;
+        if (base8 < 768) sl = std::min(nt_max, (768 + base8 - 1) / base8);
+        const int tz8 = (nt_max + sl - 1) / sl;
+        sl = (nt_max + tz8 - 1) / tz8;
+        if (mdr) hipLaunchKernelGGL((k_ntt15_colfuse8<true>), dim3(16, XP, ncf * sl), dim3(256), CF8_LDS_BYTES, st, T, src, so, dst, dso, d_cf, sl, tz8);
+        else hipLaunchKernelGGL((k_ntt15_colfuse8<false>), dim3(16, XP, ncf * sl), dim3(256), CF8_LDS_BYTES, st, T, src, so, dst, dso, d_cf, sl, tz8);
         return;
     }
     ledger_add(mdr ? "k_ntt15_colfuse<true>" : "k_ntt15_colfuse<false>", rows * XP * 262144.0);

@@ -366,6 +366,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
         const char *g = getenv("HYDIA_IP_GROUP");
         tabs.ip_group = g && atoi(g) > 0 ? atoi(g) : 8;
         tabs.generic = getenv("HYDIA_NTT_GENERIC") ? 1 : 0;
+        tabs.cf_wide = getenv("HYDIA_COLFUSE_WIDE") ? 1 : 0;
     }
     modup_per_digit = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
     loop_a_separate_ip = getenv("HYDIA_LOOPA_SEPARATE_IP") != nullptr;
@@ -548,7 +549,7 @@ DbLayout Context::db_layout_for(size_t cts, int form) const {
 }
 void Context::db_resize(size_t n_vectors, size_t cts, int form) {
     const DbLayout want = db_layout_for(cts, form);
-    const size_t bytes = cts * want.ct_bytes + 64;  // (+ the tail a lane's last 16-byte load may touch)
+    const size_t bytes = db_alloc_size(want, cts);  // (+ the tail a lane's last 16-byte load may touch: db_layout.h)
     if (d_db) sync_all();  // the layout may change under a still asynchronous query
     if (d_db && db_alloc_bytes != bytes) {
         HIP_CHECK(hipFree(d_db));
@@ -582,7 +583,7 @@ void Context::db_relayout(int form) {
             if (fresh) (void)hipFree(fresh);
         }
     } s{this};
-    const size_t bytes = db_cts * want.ct_bytes + 64;
+    const size_t bytes = db_alloc_size(want, db_cts);
     hipError_t e = hipMalloc((void **)&s.fresh, bytes);
     if (e != hipSuccess) {
         pool.trim();  // cached evaluator temporaries may be what stands in the way

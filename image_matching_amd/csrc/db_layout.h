@@ -42,3 +42,10 @@ HD size_t db_offset(const DbLayout &L, int N, size_t t, int p, int j, size_t c) 
     const size_t in_unit = (L.bits46 && L.packed && j > 0) ? (cc >> 4) * 92 : cc * es;
     return (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + unit + in_unit;
 }
+
+// first byte of the 16-byte load lane `lane` of a loop-B wave issues inside a 46-bit unit (its two residues start at bit 92 lane)
+HD size_t db_lane_load46(int lane) { return (size_t)((lane * 92) >> 5) * 4; }
+// bytes EVERY allocator of a resident database asks for: the layout's bytes plus a tail — lane 63's load ends 4 bytes past its 736-byte
+// unit, i.e. past the allocation when the unit is the last one (tests/csrc/db_layout_check.cpp checks the bound)
+constexpr size_t DB_ALLOC_TAIL = 64;
+HD size_t db_alloc_size(const DbLayout &L, size_t cts) { return cts * L.ct_bytes + DB_ALLOC_TAIL; }

@@ -893,6 +893,9 @@ bool Context::prod_fusable(int nl) const {
 Ct Context::mult_relin_rescale(const Ct &a, const Ct &b, bool dbl, const Ct *sub, const double *addc, bool sub_is_add, const Ct *csub) {
     if (a.X != b.X || a.nl != b.nl || a.npoly != 2 || b.npoly != 2) throw std::runtime_error("hydia: mult shape mismatch");
     if (csub && (csub->X != a.X || csub->npoly != 2 || csub->nl != a.nl || !dbl)) throw std::runtime_error("hydia: mult-sub shape mismatch");
+    // (no epilogue handles a product's subtrahend K c AND a `sub` operand at once — mode 10 would drop kap c while the dropped limb's tail
+    // kept it; no caller asks for both: cheb_step passes csub, the Paterson-Stockmeyer nodes pass sub)
+    if (csub && sub) throw std::logic_error("hydia: mult_relin_rescale takes a product subtrahend (csub) or a sub operand, not both");
     const int nl = a.nl, l = nl - 1, nd = (nl + alpha - 1) / alpha;
     // (the tail's subtrahend path exists in the three-and-more-digit kernels only: the steps with a subtrahend run at >= 9 limbs)
     if (!prod_fusable(nl) || (csub && (!prod_fuse_csub || nd < 3)) || (sub && (sub->X != a.X || sub->npoly != 2 || sub->nl < l))) {

@@ -589,7 +589,7 @@ DEV DbWalk db_walk(const DbLayout &L, int N, int dim, int j, int tile, int lane,
     } else {
         const size_t groups = L.blocks / L.seq, ub = db_unit_bytes(L, j);
         // (bits46: the lane's two residues start at bit 92 lane of the unit; it loads 16 bytes from the dword that holds that bit)
-        const size_t in_unit = (L.bits46 && j > 0) ? (size_t)((lane * 92) >> 5) * 4 : (size_t)lane * 2 * es;
+        const size_t in_unit = (L.bits46 && j > 0) ? db_lane_load46(lane) : (size_t)lane * 2 * es;
         w.base = (size_t)L.blocks * L.bd * 2 * db_limb_offset(L, N, j) + ((((size_t)tile * groups + grp) * L.bd) * L.seq + u0) * 2 * ub + in_unit;
         w.su = 2 * ub;
         w.si = (size_t)L.seq * 2 * ub;
@@ -1190,7 +1190,7 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
         char n0[64], n1[64];
         snprintf(n0, sizeof n0, "k_hydia_tensor<%d, %d, true, false>", BPP, NW);
         snprintf(n1, sizeof n1, h24 ? (L.bits46 ? "k_hydia_tensor24<%d, %d, true, true>" : "k_hydia_tensor24<%d, %d, false, false>") : "k_hydia_tensor<%d, %d, true, true>", BPP, NW);  // as rocprofv3 prints the instantiation
-        if (L.packed && G <= 8) snprintf(n0, sizeof n0, "k_hydia_tensor_sk<%d, false>", G <= 2 ? 16 : 4);
+        if (L.packed && G <= 8) snprintf(n0, sizeof n0, "k_hydia_tensor_sk<%d, false>", G <= 2 ? 8 : 4);
         if (L.packed) {
             ledger_add(n0, (double)G * dim * 2 * per_lp8 + rot_acc);
             if (nl > 1) ledger_add(n1, (nl - 1) * ((double)G * dim * 2 * per_lp6 + rot_acc));
@@ -1200,7 +1200,8 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
     }
     if (L.packed) {  // limb 0 (8-byte residues) and limbs 1.. (6-byte residues) as two launches: no shared register budget
         if (G <= 2)  // few blocks: 256 x G one-wave workgroups cannot hide the latency of 512 dependent steps -> split the diagonals
-            hipLaunchKernelGGL((k_hydia_tensor_sk<16, false>), dim3((N / 128) * G, 1), dim3(64 * 16), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0, ng, nblk);
+            // (eight waves: sixteen hold a lane to 128 registers and the kernel spilled 69 of them — round 5)
+            hipLaunchKernelGGL((k_hydia_tensor_sk<8, false>), dim3((N / 128) * G, 1), dim3(64 * 8), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0, ng, nblk);
         else if (G <= 8)
             hipLaunchKernelGGL((k_hydia_tensor_sk<4, false>), dim3((N / 128) * G, 1), dim3(64 * 4), 0, st, mod, N, rot, dbb, acc, dim, nl, L, 0, ng, nblk);
         else
@@ -1221,12 +1222,15 @@ static void launch_tensor(hipStream_t st, const ModC *mod, int N, const u64 *rot
                            Gq, xm, L, 0, ng, nblk);
     }
 }
-// bpp = database blocks per wave, nw = max waves per workgroup (0: up to 16); both must divide G
+// bpp = database blocks per wave (1 or 2), nw = max waves per workgroup (1, 2 or 4; 0 = 4); both must divide G.  Round 5: four blocks
+// per wave and eight / sixteen waves per workgroup are gone — they spilled (863 registers at <4,16>, 237 at <4,8>) and were never
+// faster (profiles/r04/experiments.txt: BPP=4 140.5 ms, NW=8 inside the run-to-run spread); larger values are clamped.
 void tensor_split(int G, int bpp, int nw, int *Bo, int *Wo) {
-    const int B = (bpp >= 4 && G % 4 == 0) ? 4 : (bpp >= 2 && G % 2 == 0) ? 2 : 1;
+    const int B = (bpp >= 2 && G % 2 == 0) ? 2 : 1;
     const int rest = G / B;
+    if (nw == 0 || nw > 4) nw = 4;
     int W = 1;
-    for (int cand : {16, 8, 4, 2})
+    for (int cand : {4, 2})
         if ((nw == 0 || cand <= nw) && rest % cand == 0) {
             W = cand;
             break;
@@ -1247,9 +1251,8 @@ void hydia_tensor_accumulate(hipStream_t st, const ModC *mod, int N, const u64 *
     }
 #define HY_TENSOR_CASE(b, w) \
     if (B == b && W == w) return launch_tensor<b, w>(st, mod, N, rot, db, acc, G, dim, nl, L, ng);
-    HY_TENSOR_CASE(4, 16) HY_TENSOR_CASE(4, 8) HY_TENSOR_CASE(4, 4) HY_TENSOR_CASE(4, 2) HY_TENSOR_CASE(4, 1)
-    HY_TENSOR_CASE(2, 16) HY_TENSOR_CASE(2, 8) HY_TENSOR_CASE(2, 4) HY_TENSOR_CASE(2, 2) HY_TENSOR_CASE(2, 1)
-    HY_TENSOR_CASE(1, 16) HY_TENSOR_CASE(1, 8) HY_TENSOR_CASE(1, 4) HY_TENSOR_CASE(1, 2) HY_TENSOR_CASE(1, 1)
+    HY_TENSOR_CASE(2, 4) HY_TENSOR_CASE(2, 2) HY_TENSOR_CASE(2, 1)
+    HY_TENSOR_CASE(1, 4) HY_TENSOR_CASE(1, 2) HY_TENSOR_CASE(1, 1)
 #undef HY_TENSOR_CASE
     throw std::logic_error("hydia: no loop B kernel for this split");
 }

@@ -3,6 +3,7 @@
 // layout the bytes a loop-B workgroup reads (one 128-residue tile of one limb of one group of blocks, every diagonal, both
 // polynomials) are ONE contiguous run.
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -40,6 +41,15 @@ static int check(int N, int nQ, int packed, int bd, int blocks, int gs, int bits
                 }
     for (size_t k = 0; k < total; k++)
         if (!used[k]) return printf("hole at byte %zu\n", k), 1;
+    if (L.bits46) {  // the widest access: lane 63's 16-byte load inside the LAST unit of the allocation must end inside db_alloc_size
+        size_t last = 0;
+        for (size_t t = 0; t < cts; t++)
+            for (int p = 0; p < 2; p++)
+                for (int j = 1; j < nQ; j++)
+                    for (size_t c = 0; c < (size_t)N; c += 128) last = std::max(last, db_offset(L, N, t, p, j, c));
+        if (last + db_lane_load46(63) + 16 <= total) return printf("lane 63 stays inside the unit: the tail would be dead weight\n"), 1;
+        if (last + db_lane_load46(63) + 16 > db_alloc_size(L, cts)) return printf("lane 63's load ends past the allocation\n"), 1;
+    }
     if (gs) {  // one workgroup's bytes: limb j, tile, group -> [diagonal][block in group][polynomial][128 residues] back to back
         for (int j = 0; j < nQ; j++)
             for (int tile = 0; tile < N / 128; tile++)

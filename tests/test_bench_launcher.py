@@ -45,9 +45,13 @@ def test_world_size_mismatch_is_refused():
 
 def test_external_launcher_still_works():
     """the driver's N > 1 command shape: torch.distributed.run starts the ranks, bench.py must not start more"""
+    import socket
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    with socket.socket() as sk:  # a free port, not a fixed one (back-to-back runs on one box collided on a port in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", BENCH, "--gpus", "2", "--selftest-launcher"], env=e, capture_output=True, text=True, timeout=300)
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--selftest-launcher"], env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["ranks_initialised"] == 2 and out["self_launched"] is False
@@ -61,3 +65,25 @@ def test_more_ranks_than_gpus_is_refused_before_anything_starts():
         pytest.skip("this machine has the GPUs: nothing to refuse")
     r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert r.returncode == 2 and "GPU(s) visible" in r.stderr
+
+
+def test_step_model_and_stream_ceiling_come_from_committed_profiles():
+    """bench.py --gpus N prints DESIGN section 7's prediction beside the measured step: from profiles/scaling_model.json, for the two
+    modelled databases (BASELINE configs 5 and 4); the stream ceiling is parsed from the newest committed stream_rate.txt"""
+    sys.path.insert(0, ROOT)
+    import bench
+    for lg, world in ((20, 8), (20, 2), (17, 4)):
+        for mode in ("local", "replicated", "split"):
+            m = bench.model_step(lg, world, mode)
+            assert m["mode"] == mode and m["unmeasured_on_multi_gpu_hardware"] is True
+            assert abs(m["predicted_ms_per_step"] - (m["terms"]["compute_ms"] + m["terms"]["comm_ms"])) < 1e-3
+    assert bench.model_step(20, 8, "local")["predicted_ms_per_step"] < bench.model_step(20, 2, "local")["predicted_ms_per_step"]
+    assert bench.model_step(15, 2, "local") is None  # not a modelled configuration
+    gbs, src = bench.stream_ceiling()
+    assert 6000 < gbs < 8000 and src.startswith("profiles/r") and src.endswith("stream_rate.txt")
+
+
+def test_straggler_after_rank0_is_stopped(tmp_path):
+    """rank 0 finishes, another rank hangs: the launcher stops it after the grace period and the run fails"""
+    r = run(["--gpus", "2", "--selftest-launcher"], HYDIA_BENCH_SELFTEST_HANG_RANK="1", HYDIA_BENCH_STRAGGLER_S="3")
+    assert r.returncode == 5 and "still run" in r.stderr

@@ -96,3 +96,12 @@ def test_bench_gpus_flag_runs_two_real_ranks_on_this_gpu():
     rf = out["roofline"]
     assert 0 < rf["frac"] <= 1.0 and rf["algorithmic_frac"] >= rf["frac"]
     assert rf["step"]["inherent_bytes"] > rf["bytes_per_launch"] and 0 < rf["step"]["frac"] < rf["frac"] + 1e-9
+    # round 5: an N > 1 line explains itself — communication / compute per rank (max and min), the loop-A mode, every phase of the
+    # sharded sender, and the phases of rank 0 add up to the instrumented step
+    sp = out["step_split"]
+    assert set(out["comm_ms"]) == {"max", "min"} and set(out["compute_ms"]) == {"max", "min"} and out["compute_ms"]["max"] > 0
+    assert out["loop_a_mode"] in ("local", "split", "replicated")
+    assert {"query_broadcast", "form_check", "local_matvec_comparator", "result_gather"} <= set(sp["phases_ms"]) and len(sp["per_rank_ms"]) == 2
+    assert abs(sp["rank0_sum_ms"] - sp["instrumented_ms_per_step"]) <= 0.10 * sp["instrumented_ms_per_step"], sp
+    assert "model" in out  # (2^15 in all is not a modelled configuration: null; tests/test_bench_launcher.py checks the model itself)
+    assert rf["stream_ceiling"]["source"].startswith("profiles/") and rf["vs_measured_stream_ceiling"] > 0

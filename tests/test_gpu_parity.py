@@ -323,6 +323,54 @@ def test_custom_prime_chain_context_bit_exact(im):
         im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=moduli, roots=moduli, n_p=4)
 
 
+def test_group_sequential_custom_chain_with_46bit_prime_small_ring(im):
+    """The adapter path's corner: a caller-supplied chain in which ONE scaling prime is at least 2^46 cannot take the
+    46-bit residue units, so a group-sequential database (more than 8 blocks, hoisted) falls back to 48-bit units on that context
+    (context.cpp db_relayout, capi.cpp hydia_db_residue_bits).  Enrolled ciphertexts, computeSimilarity and indexScenario of a
+    10-block database equal the oracle's on the same chain, bit for bit."""
+    from sympy import isprime
+    moduli, roots = O.alt_prime_chain(11)
+    M = 2 << 11
+    c = (1 << 46) + (1 << 40)
+    c += 1 - c % M
+    while not isprime(c):
+        c += M
+    assert (1 << 46) <= c < (1 << 47)
+    x = 2
+    while pow(pow(x, (c - 1) // M, c), M // 2, c) != c - 1:
+        x += 1
+    moduli, roots = moduli.copy(), roots.copy()
+    moduli[5], roots[5] = c, pow(x, (c - 1) // M, c)
+    P = O.Params(log_n=11, depth=11, dim=64, moduli=moduli, roots=roots, n_p=4)
+    K = O.Keys(P, 3)
+    Or = O.Oracle(P, K)
+    cc = im.Context(im.default_params(log_n=11, vector_dim=64), 0, moduli=moduli, roots=roots, n_p=4)
+    assert np.array_equal(cc.moduli, moduli)
+    cc.keygen(3)
+    blocks = 10
+    n = blocks * P.slots - 3
+    rng = np.random.default_rng(46)
+    db = rng.integers(-99, 100, size=(n, P.dim)).astype(np.float64)
+    db[n // 2] = rng.integers(1, 4, size=P.dim)
+    query = np.ones(P.dim)
+    dbc = Or.enroll(db.copy(), 4, matvec="hoisted")
+    cc.set_matvec("hoisted")
+    im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=4)
+    assert cc.db_kind() == 5 and cc.db_group() == 2 and cc.db_residue_bits() == 48  # group-sequential, 48-bit fallback
+    for t in (0, P.dim + 5, len(dbc) - 1):
+        assert np.array_equal(cc.db_export_ct(t), dbc[t].data()), t
+    q = Or.encrypt_query(query, 6, 1)
+    gq = im.DiagonalReceiver(cc, n).encryptQuery(query, seed=6, nonce=1)
+    assert np.array_equal(gq.export()[0], q.data())
+    sender = im.DiagonalSender(cc, n)
+    sim, gsim = Or.compute_similarity(q, dbc, n), sender.computeSimilarity(gq).export()
+    idx, gidx = Or.index_scenario(q, dbc, n), sender.indexScenario(gq).export()
+    assert len(sim) == blocks
+    for g in range(blocks):
+        assert np.array_equal(gsim[g], sim[g].data()) and np.array_equal(gidx[g], idx[g].data()), g
+    cc.close()
+
+
 def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
     """Every fast-path decision at N = 2^15 is bit-neutral: the default engine (FP64 NTT butterflies on the 45-bit limbs, 48-bit
     packed database and rotation keys, merged ModDown+Rescale, NTT pass 2 fused with the inner product, two comparator lanes) and the plain one
