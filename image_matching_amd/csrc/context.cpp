@@ -371,6 +371,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     modup_per_digit = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
     loop_a_separate_ip = getenv("HYDIA_LOOPA_SEPARATE_IP") != nullptr;
     loop_a_int_ip = getenv("HYDIA_LOOPA_INT_IP") != nullptr;
+    loop_a_limb_fastest = getenv("HYDIA_LOOPA_LIMB_FASTEST") != nullptr;
     relin_separate_intt = getenv("HYDIA_RELIN_SEPARATE_INTT") != nullptr;
     tabs.pm_mask = 0;  // OpenFHE's 60-bit primes sit just below 2^60 (q_0 = 2^60 - 0x3ffff, ...): HYDIA_NTT_INT / HYDIA_NTT_NO_PM keep Harvey [0, 4q)
     if (!getenv("HYDIA_NTT_INT") && !getenv("HYDIA_NTT_NO_PM"))

@@ -373,6 +373,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
             stp.la.packed_nQ = keys_packed_nQ;
             stp.la.premul = premul ? 1 : 0;
             stp.la.fp = loop_a_int_ip ? 0 : 1;
+            stp.la.limb_fastest = loop_a_limb_fastest ? 1 : 0;
             if (cfu) hk::ntt15_forward_p2_fused(stream, tabs, conv, (size_t)nl * N, Xc * 2, qsel, stp);
             else hk::ntt15_forward_fused(stream, tabs, conv, conv, (size_t)nl * N, (size_t)nl * N, Xc * 2, qsel, ld, stp);
             pool.put(conv);

@@ -303,7 +303,7 @@ struct Context : HostParams {
     int tensor_bpp = 2;             // DB blocks per wave in loop B (HYDIA_TENSOR_BPP; 4 spills past 168 VGPRs)
     int tensor_nw = 4;              // max waves per workgroup in loop B (HYDIA_TENSOR_NW; 0 = up to 16)
     // round-2 fusions, each with its off switch for the parity variants (read once per context)
-    bool modup_per_digit = false, loop_a_separate_ip = false, loop_a_int_ip = false, relin_separate_intt = false;
+    bool modup_per_digit = false, loop_a_separate_ip = false, loop_a_int_ip = false, relin_separate_intt = false, loop_a_limb_fastest = false;
     void add_inplace(Ct &a, const Ct &b);
     void sub_inplace(Ct &a, const Ct &b);
     void add_const(Ct &a, double c);

@@ -129,6 +129,7 @@ struct LoopAIp {
                              // nQ, nl for the special-prime limbs whose sums enter the ModDown inverse transform directly)
     int fp;                  // primes below 2^47: products on the FP64 pipe (bit-identical; HYDIA_LOOPA_INT_IP turns it off)
     int premul;              // keys (Q-limb rows) and the converted rows already carry P^{-1}: the combine is a plain subtraction
+    int limb_fastest;        // HYDIA_LOOPA_LIMB_FASTEST: round 4's workgroup order in the last pass (limbs fastest instead of rotations)
     int raw_fp;              // (set at launch) fp && premul: the epilogue takes the FP64 sums unreduced and reduces once (p2_finish5_fp)
 };
 struct NttStore {

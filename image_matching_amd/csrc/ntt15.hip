@@ -997,7 +997,13 @@ __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : (!INV && ST == 10) ? 4
     constexpr bool SWZ = false;
     __shared__ u64 lds[NP][P2Lds<SWZ>::SIZE];
     const int y = blockIdx.y;
-    const int xp = y / nsl, slot = slot0 + (y - xp * nsl), m = sel.mod[slot];
+    // Loop A's last pass (ST 5, forward) walks the rotations FASTEST: the workgroups in flight then share ONE limb's digit tiles (3 digits x
+    // 16 KiB per chunk), which stay in L2 between rotations.  Limb-fastest (every other launch: its operands are per-polynomial), the
+    // 9.4 MB of digits were re-fetched through the fabric about every second time (PMC: 18.0 GB fetched for 12.3 GB of operands,
+    // profiles/r05/loop_a_pmc_before.txt).  HYDIA_LOOPA_LIMB_FASTEST restores the old order (stp.la.limb_fastest).
+    const bool rot_fastest = !INV && ST == 5 && !stp.la.limb_fastest;
+    const int nxp = gridDim.y / nsl;
+    const int xp = rot_fastest ? y % nxp : y / nsl, slot = slot0 + (rot_fastest ? y / nxp : y - xp * nsl), m = sel.mod[slot];
     const ModC M = T.mod[m];
     const bool fp = (T.fp_mask >> m) & 1u;
     const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
