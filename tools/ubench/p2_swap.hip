@@ -222,6 +222,67 @@ __global__ __launch_bounds__(256) void k_p2(const ulonglong2 *__restrict__ tw, M
     }
 }
 
+
+// wave-lds with the NEXT item's operands requested before the current one is transformed (software pipelining over `nit` items per
+// workgroup: items = (polynomial pair, chunk), item i of workgroup b = b + i * gridDim.x): does a deeper load queue raise the HBM rate?
+template <class A>
+__global__ __launch_bounds__(256) void k_p2_pf(const ulonglong2 *__restrict__ tw, ModC M, const u64 *__restrict__ src, u64 *__restrict__ dst, int nit) {
+    constexpr int NP = 2, N = 32768;
+    typedef typename A::T T;
+    __shared__ u64 lds[NP][IMG];
+    const A ar(M);
+    const int t = threadIdx.x, blk = t >> 5, w = t & 31, a = w >> 2, b = w & 3;
+    u64 nxt[NP][8];
+    auto request = [&](int item) {
+        const int B0 = (item & 15) * 2048, pair = item >> 4;
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) nxt[p][k] = src[(size_t)(pair * NP + p) * N + B0 + blk * 256 + 32 * k + w];
+    };
+    request(blockIdx.x);
+    for (int it = 0; it < nit; it++) {
+        const int item = blockIdx.x + it * gridDim.x, B0 = (item & 15) * 2048, pair = item >> 4, bg = (B0 >> 8) + blk;
+        u64 *d[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) d[p] = dst + (size_t)(pair * NP + p) * N + B0;
+        T v[NP][8];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[p][k] = ar.from_raw(nxt[p][k]);
+        if (it + 1 < nit) request(item + gridDim.x);
+#pragma unroll
+        for (int p = 0; p < NP; p++) phase_a(ar, tw, v[p], bg);
+        TwB<A> WB;
+        WB.load(tw, 8 * bg + a);
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds[p][at(blk, k, w)] = A::to_bits(v[p][k]);
+        wave_sync();
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[p][k] = A::from_bits(lds[p][at(blk, a, 4 * k + b)]);
+            phase_b(ar, WB, v[p]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds[p][at(blk, a, 4 * k + b)] = A::to_bits(v[p][k]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int e = blk * 256 + 4 * w + 128 * hh;
+            const int u = e & 255, la = at(e >> 8, u >> 5, u & 31);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                phase_c(ar, tw, A::from_bits(lds[p][la]), A::from_bits(lds[p][la + 1]), A::from_bits(lds[p][la + 2]), A::from_bits(lds[p][la + 3]),
+                        B0 + e, d[p] + e);
+        }
+        wave_sync();
+    }
+}
+
 u64 mulmod_h(u64 a, u64 b, u64 q) { return (u64)((u128)a * b % q); }
 
 }  // namespace
@@ -303,6 +364,30 @@ int main() {
                    names[var], l2, l2 * 1e6 / (polys_l2 / 2 * 16 * 64.0), l2 * 1e-3 * clk * cus / coef_l2, hbm, coef_hbm * 16 / (hbm * 1e-3) / 1e12,
                    bad ? "MISMATCH" : "bit-identical");
             if (bad) printf("    %zu of %zu outputs differ from wg-lds\n", bad, out.size());
+        }
+        for (int nit : {2, 4, 8}) {  // software-pipelined wave-lds: HBM regime only
+            const ulonglong2 *tw = arith == 0 ? d_twf : d_twp;
+            const ModC &M = arith == 0 ? Mf : Mi;
+            const int items = polys_hbm / 2 * 16, grid = items / nit;
+            CK(hipMemset(d_dst, 0, n * 8));
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            for (int rep = 0; rep < 11; rep++) {
+                if (rep == 1) (void)hipEventRecord(e0, 0);
+                if (arith == 0) hipLaunchKernelGGL((k_p2_pf<FpA>), dim3(grid), dim3(256), 0, 0, tw, M, d_src, d_dst, nit);
+                else hipLaunchKernelGGL((k_p2_pf<IntP>), dim3(grid), dim3(256), 0, 0, tw, M, d_src, d_dst, nit);
+            }
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            ms /= 10;
+            CK(hipMemcpy(out.data(), d_dst, out.size() * 8, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < out.size(); i++) bad += out[i] != ref[i];
+            printf("  wave-lds, next item's operands requested ahead, %d items per workgroup: HBM stream %7.3f ms = %5.2f TB/s | %s\n", nit, ms,
+                   (double)polys_hbm * N * 16 / (ms * 1e-3) / 1e12, bad ? "MISMATCH" : "bit-identical");
         }
     }
     (void)mulmod_h;
