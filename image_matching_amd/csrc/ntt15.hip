@@ -638,21 +638,28 @@ struct P2Lds {
 // two groups of four consecutive coefficients 4w + 128 hh of its own block instead of 4t + 1024 hh of the workgroup's chunk — so every
 // LDS exchange is between lanes of one wave: the LDS executes a wave's instructions in order, a ds_read after a ds_write needs no
 // s_barrier, and the four waves of a workgroup never wait for each other.  Same butterflies on the same operands: bit-identical.
-// (-DHYDIA_P2_WG_SYNC builds round 4's chunk-wide phase C with its five barriers: tools/ab/ A/B builds.)
+// WGS = true is round 4's form (chunk-wide phase C behind s_barrier), kept as a parity variant of the PLAIN transforms: HYDIA_P2_WG_SYNC=1
+// runs k_ntt15_p2<*, *, 0, true> (tests/test_gpu_parity.py::test_ntt_bit_exact); -DHYDIA_P2_WG_SYNC builds every kernel that way (A/B builds).
 #ifdef HYDIA_P2_WG_SYNC
-DEV void p2_sync() { __syncthreads(); }
-DEV int p2_elem(int t, int hh) { return 4 * t + 1024 * hh; }
+constexpr bool P2_WGS_DEFAULT = true;
 #else
-DEV void p2_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler-only at this scope: LDS accesses stay on their side of the exchange
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-DEV int p2_elem(int t, int hh) { return (t >> 5) * 256 + 4 * (t & 31) + 128 * hh; }
+constexpr bool P2_WGS_DEFAULT = false;
 #endif
+template <bool WGS>
+DEV void p2_sync() {
+    if (WGS) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler-only at this scope: LDS accesses stay on their side of the exchange
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+template <bool WGS>
+DEV int p2_elem(int t, int hh) { return WGS ? 4 * t + 1024 * hh : (t >> 5) * 256 + 4 * (t & 31) + 128 * hh; }
 
 // phases B' and A' of the inverse second pass for NPI polynomials whose phase-C' output sits in lds (caller synchronised)
-template <class A, int NPI, bool SWZ = false>
+template <class A, int NPI, bool SWZ = false, bool WGS = P2_WGS_DEFAULT>
 DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[P2Lds<SWZ>::SIZE], u64 *const *d, int t, int B0) {
     typedef typename A::T T;
     typedef typename A::TW TW;
@@ -689,7 +696,7 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
             }
         }
     }
-    p2_sync();
+    p2_sync<WGS>();
     // phase A': strides 32, 64, 128
     {
         const TW W7 = A::tw(tw[128 + bg]);
@@ -724,7 +731,7 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
 // ST 6 = ST 4 for the special-prime limbs with the inverse transform's second pass appended: the two sums of a lane's four
 // coefficients go through phase C' in registers and meet the other lanes' in lds[0], lds[1] (the digits' images there are dead by
 // then: every lane reads and overwrites only its own four slots), phases B', A' follow, the raw image leaves through dinv.
-template <class A, bool INV, int NP, int ST, bool SWZ = false>
+template <class A, bool INV, int NP, int ST, bool SWZ = false, bool WGS = P2_WGS_DEFAULT>
 DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const *s, u64 *const *d, u64 (*lds)[P2Lds<SWZ>::SIZE], int t,
                  int B0, const NttStore &stp, const ModC &M, int xp0, int slot, const ulonglong2 *__restrict__ itw = nullptr,
                  u64 *const *dinv = nullptr) {
@@ -764,7 +771,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 }
             }
         }
-        p2_sync();
+        p2_sync<WGS>();
         // phase B: coefficients blk*256 + 32a + 4k + b ; stages 10,11,12 (strides 16, 8, 4)
         {
             const int ib = 8 * bg + a;
@@ -799,14 +806,14 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
             for (int hh = 0; hh < (SPLIT ? 1 : 2); hh++)
 #pragma unroll
-                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem(t, hh)), M);
-            if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem(t, 0)));
+                for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem<WGS>(t, hh)), M);
+            if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem<WGS>(t, 0)));
         }
-        p2_sync();
+        p2_sync<WGS>();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int e = p2_elem(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
+            const int e = p2_elem<WGS>(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
             // mode 4: lazy 128-bit sums of value * key over the digits this workgroup transforms (+ the limb's own digit)
@@ -816,8 +823,8 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             const int ip_own = (stp.ip.own && ip_t < stp.ip.nl) ? ip_t / stp.ip.alpha : (1 << 30);
             if (SPLIT && hh == 1) {
 #pragma unroll
-                for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem(t, 1)), M);
-                if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem(t, 1)));
+                for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem<WGS>(t, 1)), M);
+                if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem<WGS>(t, 1)));
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) {
@@ -926,14 +933,14 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             }
         }
         if (ST == 6) {
-            p2_sync();
-            p2_inverse_BA<A, 2, SWZ>(ar, itw, lds, dinv, t, B0);
+            p2_sync<WGS>();
+            p2_inverse_BA<A, 2, SWZ, WGS>(ar, itw, lds, dinv, t, B0);
         }
     } else {
         // phase C': strides 1, 2
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int e = p2_elem(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
+            const int e = p2_elem<WGS>(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
             const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
 #pragma unroll
@@ -980,13 +987,13 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 lds[p][la + 2] = A::to_bits(c2); lds[p][la + 3] = A::to_bits(c3);
             }
         }
-        p2_sync();
-        p2_inverse_BA<A, NP, SWZ>(ar, tw, lds, d, t, B0);
+        p2_sync<WGS>();
+        p2_inverse_BA<A, NP, SWZ, WGS>(ar, tw, lds, d, t, B0);
     }
 }
 
 // grid (16 chunks of 2048, (X/NP)*sel.n)
-template <bool INV, int NP, int ST>
+template <bool INV, int NP, int ST, bool WGS = P2_WGS_DEFAULT>
 // (loop A's fused inner product asks for three workgroups per CU: unbounded it takes 171 registers — two per CU, 6.24 ms per
 // rotateQuery; at 167 it keeps its twelve loads per call in flight with three, 5.95 ms; capped to 128 it spills, 6.13 ms)
 __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : (!INV && ST == 10) ? 4 : 1) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
@@ -1015,9 +1022,9 @@ __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : (!INV && ST == 10) ? 4
         s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;
         d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;
     }
-    if (fp) p2_body<FpA, INV, NP, ST, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
-    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST, SWZ>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
-    else p2_body<IntA, INV, NP, ST, SWZ>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    if (fp) p2_body<FpA, INV, NP, ST, SWZ, WGS>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST, SWZ, WGS>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    else p2_body<IntA, INV, NP, ST, SWZ, WGS>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
 }
 
 // second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
@@ -1520,6 +1527,13 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
     NttStore sv = stp;
     sv.int_epilogue = T.int_epilogue;
     if (ST == 5) sv.la.raw_fp = (stp.la.fp && stp.la.premul && !stp.dbl && !T.int_epilogue && T.twf != nullptr) ? 1 : 0;
+    if (ST == 0 && T.p2_wg_sync) {  // parity variant of the plain transform: round 4's workgroup-synchronous pass 2
+        if (pair_polys(X, nsl))
+            hipLaunchKernelGGL((k_ntt15_p2<false, 2, 0, true>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
+        else
+            hipLaunchKernelGGL((k_ntt15_p2<false, 1, 0, true>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
+        return;
+    }
     if (pair_polys(X, nsl))
         hipLaunchKernelGGL((k_ntt15_p2<false, 2, ST>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
     else
@@ -1664,7 +1678,12 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
         }
         ledger_add(pair_polys(X, n) ? "k_ntt15_p2<true, 2, 0>" : "k_ntt15_p2<true, 1, 0>", 2.0 * X * n * 262144.0);
         ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * n * 262144.0);
-        if (pair_polys(X, n))
+        if (T.p2_wg_sync) {
+            if (pair_polys(X, n))
+                hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0, true>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+            else
+                hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0, true>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+        } else if (pair_polys(X, n))
             hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
         else
             hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);

@@ -54,10 +54,16 @@ def small(im):
     cc.close()
 
 
-@pytest.mark.parametrize("log_n", [11, 13, 15])
-def test_ntt_bit_exact(im, log_n):
+@pytest.mark.parametrize("log_n,env", [(11, None), (13, None), (15, None), (15, "HYDIA_P2_WG_SYNC")])
+def test_ntt_bit_exact(im, log_n, env, monkeypatch):
+    """(15, HYDIA_P2_WG_SYNC): the plain N = 2^15 transforms through round 4's workgroup-synchronous pass 2 (chunk-wide phase C behind
+    s_barrier) — the parity variant of round 5's wave-synchronous default"""
     P = O.Params(log_n=log_n, depth=11, dim=64)
+    if env:
+        monkeypatch.setenv(env, "1")
     cc = make_ctx(im, P)
+    if env:
+        monkeypatch.delenv(env)
     rng = np.random.default_rng(log_n)
     for m in (0, 1, 6, 11, 12, 15):
         q = int(P.moduli[m])
