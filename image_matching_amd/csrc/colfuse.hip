@@ -5,6 +5,7 @@
 // RelinearizeInPlace + RescaleInPlace (:79-80) and the ct x ct products of chebyshevCompare (src/openFHE_wrapper.cpp:143-185).
 #include <algorithm>
 #include <cstdlib>
+#include <stdexcept>
 
 #include "kernels.h"
 #include "ntt_arith.h"
@@ -25,7 +26,7 @@ namespace {
 // Merged ModDown + Rescale (MDR) carries a fifth value per row, the dropped limb's centred residue: it lives in the second image's
 // LDS (one slot per lane and row) instead of 32 more registers — 160 + working registers spilled to scratch (1.43 against 2.1 TB/s) —
 // and that variant exchanges through ONE image with a second barrier per transform.
-constexpr int CF_LDS_BYTES = 2 * 128 * 32 * 8 + (HY_CF_SRC + 1 + 2) * 128 * 16;
+constexpr int CF_LDS_BYTES = 2 * 128 * 32 * 8 + (HY_CF_SRC + 1 + 2) * 128 * 16;  // (the wide kernel serves four sources)
 
 // y: in = raw pass-2' values of rows 8h + l (h = g + 8 hh) at index 8 hh + l; out = canonical coefficient-form residues (times sc) of
 // rows g + 8k at index k
@@ -80,22 +81,26 @@ DEV void cf_inverse(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 // a = H 2^60 + L with L = ll + (mid mod 2^32) 2^30 < 2^63 and H = hh + 4 (mid >> 32), which is all either reduction needs.
 // Sources are kept in the split form (yl in the low dword, yh in the high one: the same two registers).
 DEV u64 cf_split30(u64 v) { return (v & 0x3FFFFFFFull) | ((v >> 30) << 32); }
-struct CfConst {
-    unsigned lo[HY_CF_SRC], hi[HY_CF_SRC];
+template <int NS>
+struct CfConstN {
+    unsigned lo[NS], hi[NS];
     DEV void set(int s, u64 f) {
         lo[s] = (unsigned)f & 0x3FFFFFFFu;
         hi[s] = (unsigned)(f >> 30);
     }
 };
+typedef CfConstN<HY_CF_SRC> CfConst;
 struct CfSum {
     u64 L, H;
     DEV u128 wide() const { return (u128)L + ((u128)H << 60); }
 };
-DEV CfSum cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
-    const u64 y[HY_CF_SRC] = {y0, y1, y2, y3};
+// (NS = 5, round 5: five sources BELOW 2^48 — yh < 2^18 — keep every bound: ll < 5 2^60 < 2^63, mid < 5 (2^60 + 2^48) < 2^63, hh < 5 2^48, so
+// L < 2^63 and H < 2^51; the launcher refuses five sources with a wider modulus)
+template <int NS>
+DEV CfSum cf_macN(const u64 (&y)[NS], const CfConstN<NS> &f) {
     u64 pll = 0, pmid = 0, phh = 0;
 #pragma unroll
-    for (int s = 0; s < HY_CF_SRC; s++) {
+    for (int s = 0; s < NS; s++) {
         const unsigned yl = (unsigned)y[s], yh = (unsigned)(y[s] >> 32);
         pll += (u64)yl * f.lo[s];
         pmid += (u64)yl * f.hi[s];
@@ -106,6 +111,18 @@ DEV CfSum cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
     r.L = pll + ((pmid & 0xFFFFFFFFull) << 30);
     r.H = phh + ((pmid >> 32) << 2);
     return r;
+}
+DEV CfSum cf_mac4(u64 y0, u64 y1, u64 y2, u64 y3, const CfConst &f) {
+    const u64 y[HY_CF_SRC] = {y0, y1, y2, y3};
+    return cf_macN<HY_CF_SRC>(y, f);
+}
+// row k of NS sources held as y[s][k]
+template <int NS, int NR>
+DEV CfSum cf_mac_row(const u64 (&y)[NS][NR], int k, const CfConstN<NS> &f) {
+    u64 yy[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) yy[s] = y[s][k];
+    return cf_macN<NS>(yy, f);
 }
 // FP64 targets (q < 2^47, so f < 2^47 and H < 2^50): the transform is linear and exact on ANY representative below ~2 q in magnitude
 // (growth 0.75 q per stage, 15 stages, headroom 2^52), so the sum is folded in FP64 instead of being reduced to the canonical residue:
@@ -177,12 +194,12 @@ DEV void cf_forward(const A ar, const ulonglong2 *__restrict__ tw, const ulonglo
 // last digit) hold zeros, so the sum is branch-free: four lazy 128-bit multiply-accumulates.
 // Integer targets (the 60-bit limb 0): canonical residue, single-word Barrett on the top bits (reduce128k: at most four products of
 // residues below 2^60 with constants below q).
-template <class A, bool MDR, int NR>
-DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][NR], const u64 *um /* [k * 256] */,
+template <class A, bool MDR, int NR, int NS>
+DEV void cf_convert(const A ar, const ModC &M, const CfConstN<NS> &f, const u64 (&y)[NS][NR], const u64 *um /* [k * 256] */,
                     unsigned neg, typename A::T (&v)[NR], bool nosrc) {
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        u64 r = nosrc ? 0 : reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f).wide(), M);
+        u64 r = nosrc ? 0 : reduce128k(cf_mac_row(y, k, f).wide(), M);
         if (MDR) {
             const u64 c = reduce64(um[k * 256], M);
             r = addmod(r, ((neg >> k) & 1u) ? negmod(c, M.q) : c, M.q);
@@ -193,14 +210,14 @@ DEV void cf_convert(const A ar, const ModC &M, const CfConst &f, const u64 (&y)[
 // Pseudo-Mersenne targets (q_0 and the special primes, 2^60 - c): the two-word sum is FOLDED (IntP::fold_lh, four multiply-adds) to a
 // lazy representative below 2.07 2^60 instead of Barrett-reduced — with the dropped limb's residue (at most q) the forward
 // butterflies start below 3.1 q and reach 15.1 q at their first fold (bound 16 q).
-template <bool MDR, int NR>
-DEV void cf_convert(const IntP ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][NR], const u64 *um /* [k * 256] */,
+template <bool MDR, int NR, int NS>
+DEV void cf_convert(const IntP ar, const ModC &M, const CfConstN<NS> &f, const u64 (&y)[NS][NR], const u64 *um /* [k * 256] */,
                     unsigned neg, u64 (&v)[NR], bool nosrc) {
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         u64 r = 0;
         if (!nosrc) {
-            const CfSum a = cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f);
+            const CfSum a = cf_mac_row(y, k, f);
             r = ar.fold_lh(a.L, a.H);
         }
         if (MDR) {
@@ -210,12 +227,12 @@ DEV void cf_convert(const IntP ar, const ModC &M, const CfConst &f, const u64 (&
         v[k] = r;
     }
 }
-template <bool MDR, int NR>
-DEV void cf_convert(const FpA ar, const ModC &M, const CfConst &f, const u64 (&y)[HY_CF_SRC][NR], const u64 *um /* [k * 256] */,
+template <bool MDR, int NR, int NS>
+DEV void cf_convert(const FpA ar, const ModC &M, const CfConstN<NS> &f, const u64 (&y)[NS][NR], const u64 *um /* [k * 256] */,
                     unsigned neg, double c60, double (&v)[NR], bool nosrc) {
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        double r = nosrc ? 0.0 : cf_fold(ar, cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], f), c60);
+        double r = nosrc ? 0.0 : cf_fold(ar, cf_mac_row(y, k, f), c60);
         if (MDR) {
             const double c = FpA::u2d(um[k * 256]);  // |centred residue| < 2^59: exact only below 2^52 — dropped limbs are scaling primes (< 2^47)
             r += ((neg >> k) & 1u) ? -c : c;
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt15_colfuse(NttTables T, const u64
 // through 16 KiB images — same butterflies on the same operands, same folds: bit-identical — at <= 168 registers and 46 KiB of LDS:
 // three workgroups per CU, or two beside other kernels' workgroups.  HYDIA_COLFUSE_WIDE=1 runs the kernel above.
 constexpr int CF8_COLS = 16, CF8_IMG = 128 * CF8_COLS;
-constexpr int CF8_LDS_BYTES = 2 * CF8_IMG * 8 + (HY_CF_SRC + 1 + 2) * 128 * 16;
+constexpr int CF8_LDS_BYTES = 2 * CF8_IMG * 8 + (HY_CF_SRC_MAX + 1 + 2) * 128 * 16;
 
 // y: in = raw pass-2' values of rows 8g + m at index m; out = canonical coefficient-form residues (times sc) of rows g + 16k at index k
 template <class A>
@@ -492,14 +509,15 @@ DEV void cf_forward8(const A ar, const ulonglong2 *__restrict__ tw, const ulongl
 }
 
 // grid (16 column tiles, XP polynomials, ncf maps x target slices), 256 threads: col = t & 15, g = t >> 4
-template <bool MDR>
-__global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
+// NS: conversion sources held per lane — 4, or 5 for a ModDown over five special primes below 2^48 (two workgroups per CU then)
+template <bool MDR, int NS = HY_CF_SRC>
+__global__ __launch_bounds__(256, NS > HY_CF_SRC ? 2 : 3) void k_ntt15_colfuse8(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
                                                             size_t dso, const ColFuse *__restrict__ cfs, int slices, int tz) {
     constexpr int N = 32768;
     extern __shared__ __attribute__((aligned(16))) u64 cf_smem[];
     u64 *const img = cf_smem;  // two exchange images of 128 x 16
-    ulonglong2 *const sltw = reinterpret_cast<ulonglong2 *>(cf_smem + 2 * CF8_IMG);  // [HY_CF_SRC + 1][128]
-    ulonglong2 *const tltw = sltw + (HY_CF_SRC + 1) * 128;                          // [2][128]
+    ulonglong2 *const sltw = reinterpret_cast<ulonglong2 *>(cf_smem + 2 * CF8_IMG);  // [HY_CF_SRC_MAX + 1][128]
+    ulonglong2 *const tltw = sltw + (HY_CF_SRC_MAX + 1) * 128;                          // [2][128]
     const int zi = blockIdx.z / slices, zs = blockIdx.z - zi * slices;
     const ColFuse &cf = cfs[zi];
     const int t_lo = zs * tz, t_hi = min(cf.nt, t_lo + tz);
@@ -509,14 +527,14 @@ __global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u6
     const u64 *sb = src + (size_t)xp * so + c0 + col;
     // ---- every global load of the workgroup, up front: the raw pass-2' values of rows 8g + m, where pass 1' starts
     u64 *const umem = cf_smem + CF8_IMG + t;  // MDR: lane t's slot of row k at umem[k * 256] (the second image)
-    u64 y[HY_CF_SRC][8], um[8];
+    u64 y[NS][8], um[8];
     if (MDR) {
         const u64 *sp = sb + (size_t)cf.urow * N;
 #pragma unroll
         for (int m = 0; m < 8; m++) um[m] = sp[(size_t)(8 * g + m) * 256];
     }
 #pragma unroll
-    for (int s = 0; s < HY_CF_SRC; s++) {
+    for (int s = 0; s < NS; s++) {
         if (s >= cf.nk) {
 #pragma unroll
             for (int k = 0; k < 8; k++) y[s][k] = 0;
@@ -528,7 +546,7 @@ __global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u6
     }
     if (t < 128) {
 #pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++)
+        for (int s = 0; s < NS; s++)
             if (s < cf.nk) {
                 const int m = cf.smod[s];
                 const bool fp = (T.fp_mask >> m) & 1u;
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u6
         if (MDR) {
             const int m = cf.umod;
             const bool fp = (T.fp_mask >> m) & 1u;
-            sltw[HY_CF_SRC * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
+            sltw[HY_CF_SRC_MAX * 128 + t] = ((fp ? T.itwf : T.itwp) + (size_t)m * N)[t];
         }
     }
     __syncthreads();
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u6
     // MDR exchanges through image 0 only (image 1 holds the dropped limb's residues): a barrier before an image is rewritten
 #define CF8_NEXT_IMAGE() (MDR ? (__syncthreads(), img) : img + (buf ^= 1) * CF8_IMG)
     if (MDR) {
-        cf_inverse8_any(T, cf.umod, cf.uM, sltw + HY_CF_SRC * 128, CF8_NEXT_IMAGE(), g, col, cf.usc, cf.usc_sh, um, false);
+        cf_inverse8_any(T, cf.umod, cf.uM, sltw + HY_CF_SRC_MAX * 128, CF8_NEXT_IMAGE(), g, col, cf.usc, cf.usc_sh, um, false);
 #pragma unroll
         for (int k = 0; k < 8; k++) umem[k * 256] = um[k];
     }
@@ -553,18 +571,19 @@ __global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u6
     if (1 < cf.nk) cf_inverse8_any(T, cf.smod[1], cf.sM[1], sltw + 128, CF8_NEXT_IMAGE(), g, col, cf.ssc[1], cf.ssc_sh[1], y[1], true);
     if (2 < cf.nk) cf_inverse8_any(T, cf.smod[2], cf.sM[2], sltw + 256, CF8_NEXT_IMAGE(), g, col, cf.ssc[2], cf.ssc_sh[2], y[2], true);
     if (3 < cf.nk) cf_inverse8_any(T, cf.smod[3], cf.sM[3], sltw + 384, CF8_NEXT_IMAGE(), g, col, cf.ssc[3], cf.ssc_sh[3], y[3], true);
+    if (NS > 4 && 4 < cf.nk) cf_inverse8_any(T, cf.smod[NS - 1], cf.sM[NS - 1], sltw + 512, CF8_NEXT_IMAGE(), g, col, cf.ssc[NS - 1], cf.ssc_sh[NS - 1], y[NS - 1], true);
     // ---- merged ModDown + Rescale: the dropped limb of the would-be ModDown output, centred (k_moddown_rescale_conv's first half)
     unsigned neg = 0;
     if (MDR) {
         const ModC Ml = cf.lM;
         const u64 half = Ml.q >> 1;
-        CfConst fl;
+        CfConstN<NS> fl;
 #pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) fl.set(s, s < cf.nk ? cf.fl[s] : 0);
+        for (int s = 0; s < NS; s++) fl.set(s, s < cf.nk ? cf.fl[s] : 0);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const u64 yl = cf.nk == 0 ? umem[k * 256]  // a plain Rescale: the dropped limb itself
-                                      : submod(umem[k * 256], reduce128k(cf_mac4(y[0][k], y[1][k], y[2][k], y[3][k], fl).wide(), Ml), Ml.q);  // own slot: no barrier needed
+                                      : submod(umem[k * 256], reduce128k(cf_mac_row(y, k, fl).wide(), Ml), Ml.q);  // own slot: no barrier needed
             const bool ng = yl > half;
             umem[k * 256] = ng ? Ml.q - yl : yl;
             neg |= (ng ? 1u : 0u) << k;
@@ -581,12 +600,12 @@ __global__ __launch_bounds__(256, 3) void k_ntt15_colfuse8(NttTables T, const u6
         u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;  // cf_forward8 adds the lane's column
         u64 *lds = CF8_NEXT_IMAGE();
 #pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int k = 0; k < 8; k++) asm volatile("" : "+v"(y[s][k]));
-        CfConst f;
+        CfConstN<NS> f;
 #pragma unroll
-        for (int s = 0; s < HY_CF_SRC; s++) f.set(s, s < cf.nk ? cf.f[s][tt] : 0);
+        for (int s = 0; s < NS; s++) f.set(s, s < cf.nk ? cf.f[s][tt] : 0);
         const ulonglong2 ltv = tw[t & 127];
         if (fp) {
             const FpA ar(M);
@@ -739,8 +758,17 @@ void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so
         else hipLaunchKernelGGL((k_ntt15_conv_p1<false>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
         return;
     }
+    int nk_max = 0;
+    for (int i = 0; i < ncf; i++) nk_max = std::max(nk_max, h_cf[i].nk);
+    if (nk_max > HY_CF_SRC) {  // five sources (special primes below 2^48; cf_plan_* vouches): the narrow kernel's five-source instantiation only
+        if (pre || nk_max > HY_CF_SRC_MAX) throw std::logic_error("hydia: column-fused conversion with more than four sources in the small-launch form");
+        ledger_add(mdr ? "k_ntt15_colfuse8<true, 5>" : "k_ntt15_colfuse8<false, 5>", rows * XP * 262144.0);
+        if (mdr) hipLaunchKernelGGL((k_ntt15_colfuse8<true, 5>), dim3(16, XP, ncf), dim3(256), CF8_LDS_BYTES, st, T, src, so, dst, dso, d_cf, 1, nt_max);
+        else hipLaunchKernelGGL((k_ntt15_colfuse8<false, 5>), dim3(16, XP, ncf), dim3(256), CF8_LDS_BYTES, st, T, src, so, dst, dso, d_cf, 1, nt_max);
+        return;
+    }
     if (!T.cf_wide) {  // the narrow form: 16 column tiles of 16 columns
-        ledger_add(mdr ? "k_ntt15_colfuse8<true>" : "k_ntt15_colfuse8<false>", rows * XP * 262144.0);
+        ledger_add(mdr ? "k_ntt15_colfuse8<true, 4>" : "k_ntt15_colfuse8<false, 4>", rows * XP * 262144.0);  // (as rocprofv3 prints the instantiation)
         const int base8 = 16 * XP * ncf;
         int sl = 1;
         if (base8 < 768) sl = std::min(nt_max, (768 + base8 - 1) / base8);

@@ -390,7 +390,7 @@ void Context::ks_apply(const u64 *dig, size_t dig_x_stride, int X, int nl, const
     if (cf_ok()) {
         // special-prime limbs: pass 2' alone, then pass 1' + conversion + pass 1 in one column-fused launch, then pass 2 + ModDown combine
         const CfPlan &cp = cf_plan_moddown(nl, false);
-        const bool small = hk::ntt15_colfuse_small(X * 2, 1);
+        const bool small = cf_small_moddown(X * 2);
         if (small) ntt_inv(acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel, scale_of(psel, Phat_inv, true));
         else hk::ntt15_inverse_p2(stream, tabs, acc + (size_t)nl * N, y, (size_t)nE * N, (size_t)nP * N, X * 2, psel);
         hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, X * 2, cp.dev, cp.host.data(), 1, small);
@@ -506,7 +506,7 @@ void Context::ks_fused(const u64 *c1, size_t c1_xs, int X, int nl, const u64 *ke
     timer_end("ks_inner_product");
     pool.put(dig);
     const CfPlan &cp = cf_plan_moddown(nl, false);
-    const bool small = hk::ntt15_colfuse_small(XP, 1);
+    const bool small = cf_small_moddown(XP);
     if (small) hk::ntt15_inverse_p1(stream, tabs, y, (size_t)nP * N, XP, psel, scale_of(psel, Phat_inv, true));
     u64 *conv = pool.get((size_t)XP * nl * N * sizeof(u64));
     hk::ntt15_colfuse(stream, tabs, y, (size_t)nP * N, conv, (size_t)nl * N, XP, cp.dev, cp.host.data(), 1, small);
@@ -699,7 +699,7 @@ void Context::relin_rescale_into(const Ct &c, bool dbl, const Ct *sub, const dou
         tail_scale[1 + k] = Phat_inv[k];
     }
     const bool cfu = cf_ok() && (q[l] >> 50) == 0;  // the fused kernel carries the dropped limb's centred residue as a double
-    const bool cf_pre = cfu && hk::ntt15_colfuse_small(XP, 1);  // few workgroups: pass 1' as its own (wider) launch
+    const bool cf_pre = cfu && cf_small_moddown(XP);  // few workgroups: pass 1' as its own (wider) launch
     if (fused_tail) {
         if (!drop_done)
             hk::ntt15_inverse_p2_last_limb(stream, tabs, acc + (size_t)l * N, yu, (size_t)nE * N, yu_outer, XP, l, pinv_sel.s[l], pinv_sel.s_sh[l],
@@ -1398,7 +1398,12 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
     std::vector<Ct> res(L);
     Ct out;
     for (int k = 0; k < L; k++) {
-        const int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
+        int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
+        if (L == 2 && lane_split > 0.0 && G >= 4) {  // experiment knob HYDIA_LANE_SPLIT: lane 0's share of the blocks (the lanes then drift out of step)
+            const int cut = std::max(1, std::min(G - 1, (int)(G * lane_split + 0.5)));
+            g0 = k == 0 ? 0 : cut;
+            g1 = k == 0 ? cut : G;
+        }
         set_lane(k);
         if (k > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev[L], 0));
         Ct part = acc.alias(acc.nl);

@@ -111,6 +111,7 @@ struct Context : HostParams {
     hipStream_t stream = nullptr;  // the CURRENT lane's stream (lane 0 unless inside a multi-lane section)
     std::vector<hipStream_t> lane_stream;  // lane 0 = the main stream
     int nlanes = 2;                        // comparator lanes (HYDIA_LANES)
+    double lane_split = 0.0;               // HYDIA_LANE_SPLIT (experiment knob): lane 0's share of the blocks when there are two lanes; 0 = halves
     std::vector<hipEvent_t> lane_ev;
     void set_lane(int k);
     void sync_all();
@@ -244,7 +245,16 @@ struct Context : HostParams {
     const CfPlan &cf_plan_rescale(int nl);  // Rescale alone as a column-fused map without conversion sources: u -> every remaining limb     // merged ModDown + Rescale from level nl
     const CfPlan &cf_plan_store(const std::string &key, std::vector<ColFuse> &&maps);
     bool colfuse = true;        // HYDIA_NO_COLFUSE: pass 1' / conversion / pass 1 as three kernels
-    bool cf_ok() const { return colfuse && prm.logN == 15 && alpha <= HY_CF_SRC && nP <= HY_CF_SRC; }
+    // (five special primes, all below 2^48, take the five-source instantiation of the narrow column-fused kernel: the secondary
+    // "special primes on the FP64 pipe" configuration of tools/exp_fp64_special_primes.py; its ModDown conversions never take the small-launch form)
+    bool cf_ok() const {
+        if (!(colfuse && prm.logN == 15 && alpha <= HY_CF_SRC && nP <= HY_CF_SRC_MAX)) return false;
+        if (nP > HY_CF_SRC)
+            for (int k = nQ; k < nT; k++)
+                if (q[k] >> 48) return false;
+        return true;
+    }
+    bool cf_small_moddown(int XP) const { return nP <= HY_CF_SRC && hk::ntt15_colfuse_small(XP, 1); }
     LimbSel sel_q(int nl) const;           // limbs 0..nl-1
     LimbSel sel_ext(int nl) const;         // limbs 0..nl-1 then all P limbs
     LimbSel sel_range(int lo, int hi) const;

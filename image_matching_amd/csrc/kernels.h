@@ -166,21 +166,22 @@ struct NttStore {
 // ModDown + Rescale), fast base conversion, forward pass 1 of up to 16 target limbs — all on ONE 32-column tile of the 128 x 256
 // coefficient matrix, sources held in registers, so the coefficient-form rows never exist in HBM.  One entry describes one
 // (sources -> targets) map: a ModDown, or one digit of a ModUp.
-#define HY_CF_SRC 4
+#define HY_CF_SRC 4       // conversion sources of the default kernels (a digit of alpha = 4 limbs; the reference's four special primes)
+#define HY_CF_SRC_MAX 5   // round 5: a FIFTH source for ModDown maps over five special primes below 2^48 (k_ntt15_colfuse8<*, 5>; secondary figure)
 #define HY_CF_TGT 16
 struct ColFuse {
     int nk, nt;                  // conversion sources, targets
     int mdr;                     // 1: merged ModDown + Rescale — an extra source `u` (modulus l) whose centred residue is added to every target
     int l;                       // mdr: modulus id of the dropped limb
-    int smod[HY_CF_SRC], srow[HY_CF_SRC];  // modulus id / row (in src, per polynomial) of each conversion source
+    int smod[HY_CF_SRC_MAX], srow[HY_CF_SRC_MAX];  // modulus id / row (in src, per polynomial) of each conversion source
     int umod, urow;                        // mdr: the same for u
-    u64 ssc[HY_CF_SRC], ssc_sh[HY_CF_SRC]; // final multiplier of each source's inverse transform (N^{-1} x conversion factor)
+    u64 ssc[HY_CF_SRC_MAX], ssc_sh[HY_CF_SRC_MAX]; // final multiplier of each source's inverse transform (N^{-1} x conversion factor)
     u64 usc, usc_sh;
     int tmod[HY_CF_TGT], trow[HY_CF_TGT];  // modulus id / row (in dst, per polynomial) of each target
-    u64 f[HY_CF_SRC][HY_CF_TGT];           // conversion constants: target t = sum_k y_k f[k][t] mod q_tmod[t]
-    u64 fl[HY_CF_SRC];                     // mdr: constants of the dropped limb, y_l = u - sum_k y_k fl[k] mod q_l
+    u64 f[HY_CF_SRC_MAX][HY_CF_TGT];           // conversion constants: target t = sum_k y_k f[k][t] mod q_tmod[t]
+    u64 fl[HY_CF_SRC_MAX];                     // mdr: constants of the dropped limb, y_l = u - sum_k y_k fl[k] mod q_l
     u64 t60[HY_CF_TGT];                    // 2^60 mod q_tmod[t] (the FP64 fold of the conversion sums; filled by cf_plan_store)
-    ModC sM[HY_CF_SRC], uM, lM;            // the same for the sources, u and the dropped limb
+    ModC sM[HY_CF_SRC_MAX], uM, lM;            // the same for the sources, u and the dropped limb
     ModC tM[HY_CF_TGT];                    // the targets' modulus constants (a copy of NttTables::mod[tmod[t]], filled by cf_plan_store): a
                                            // target's constants then come with ONE batch of scalar loads off the map instead of a chain of
                                            // dependent ones (tmod -> mod[] -> kind -> tables) at the head of every target

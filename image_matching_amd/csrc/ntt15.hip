@@ -992,39 +992,49 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
     }
 }
 
-// grid (16 chunks of 2048, (X/NP)*sel.n)
-template <bool INV, int NP, int ST, bool WGS = P2_WGS_DEFAULT>
+// grid (16 chunks of 2048, (X/NP)*sel.n).  The body is a macro shared by the two kernels below: through a device function the NttStore
+// kernel argument would be copied to scratch (2 KiB per lane: its per-limb tables are indexed dynamically) instead of being read with scalar
+// loads from the kernel-argument segment.
+// Loop A's last pass (ST 5, forward) walks the rotations FASTEST: the workgroups in flight then share ONE limb's digit tiles (3 digits x
+// 16 KiB per chunk), which stay in L2 between rotations.  Limb-fastest (every other launch: its operands are per-polynomial), the
+// 9.4 MB of digits were re-fetched through the fabric about every second time (PMC: 18.0 GB fetched for 12.3 GB of operands,
+// profiles/r05/loop_a_pmc_before.txt).  HYDIA_LOOPA_LIMB_FASTEST restores the old order (stp.la.limb_fastest).
+// (the unpadded image would let five two-polynomial workgroups share a CU instead of four: measured, no gain — 4.05 vs 4.08 ms for
+// the merged epilogue's 23 launches of a 2^20 query — so the plain transforms keep the padded one)
+#define P2_KERNEL_BODY(ST_, WGS_)                                                                                                         \
+    constexpr int N = 32768;                                                                                                              \
+    constexpr bool SWZ = false;                                                                                                           \
+    __shared__ u64 lds[NP][P2Lds<SWZ>::SIZE];                                                                                             \
+    const int y = blockIdx.y;                                                                                                             \
+    const bool rot_fastest = !INV && ST_ == 5 && !stp.la.limb_fastest;                                                                    \
+    const int nxp = gridDim.y / nsl;                                                                                                      \
+    const int xp = rot_fastest ? y % nxp : y / nsl, slot = slot0 + (rot_fastest ? y / nxp : y - xp * nsl), m = sel.mod[slot];            \
+    const ModC M = T.mod[m];                                                                                                              \
+    const bool fp = (T.fp_mask >> m) & 1u;                                                                                                \
+    const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;                           \
+    const int B0 = blockIdx.x * 2048;                                                                                                     \
+    const u64 *s[NP];                                                                                                                     \
+    u64 *d[NP];                                                                                                                           \
+    _Pragma("unroll") for (int p = 0; p < NP; p++) {                                                                                      \
+        s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;                                                                  \
+        d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;                                                                 \
+    }                                                                                                                                     \
+    if (fp) p2_body<FpA, INV, NP, ST_, SWZ, WGS_>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);                         \
+    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST_, SWZ, WGS_>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot); \
+    else p2_body<IntA, INV, NP, ST_, SWZ, WGS_>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+template <bool INV, int NP, int ST>
 // (loop A's fused inner product asks for three workgroups per CU: unbounded it takes 171 registers — two per CU, 6.24 ms per
 // rotateQuery; at 167 it keeps its twelve loads per call in flight with three, 5.95 ms; capped to 128 it spills, 6.13 ms)
 __global__ __launch_bounds__(256, (!INV && ST == 5) ? 3 : (!INV && ST == 10) ? 4 : 1) void k_ntt15_p2(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so,
                                                   size_t dso, LimbSel sel, int slot0, int nsl, NttStore stp) {
-    constexpr int N = 32768;
-    // (the unpadded image would let five two-polynomial workgroups share a CU instead of four: measured, no gain — 4.05 vs 4.08 ms for
-    // the merged epilogue's 23 launches of a 2^20 query — so the plain transforms keep the padded one)
-    constexpr bool SWZ = false;
-    __shared__ u64 lds[NP][P2Lds<SWZ>::SIZE];
-    const int y = blockIdx.y;
-    // Loop A's last pass (ST 5, forward) walks the rotations FASTEST: the workgroups in flight then share ONE limb's digit tiles (3 digits x
-    // 16 KiB per chunk), which stay in L2 between rotations.  Limb-fastest (every other launch: its operands are per-polynomial), the
-    // 9.4 MB of digits were re-fetched through the fabric about every second time (PMC: 18.0 GB fetched for 12.3 GB of operands,
-    // profiles/r05/loop_a_pmc_before.txt).  HYDIA_LOOPA_LIMB_FASTEST restores the old order (stp.la.limb_fastest).
-    const bool rot_fastest = !INV && ST == 5 && !stp.la.limb_fastest;
-    const int nxp = gridDim.y / nsl;
-    const int xp = rot_fastest ? y % nxp : y / nsl, slot = slot0 + (rot_fastest ? y / nxp : y - xp * nsl), m = sel.mod[slot];
-    const ModC M = T.mod[m];
-    const bool fp = (T.fp_mask >> m) & 1u;
-    const ulonglong2 *__restrict__ tw = (fp ? (INV ? T.itwf : T.twf) : (INV ? T.itwp : T.twp)) + (size_t)m * N;
-    const int B0 = blockIdx.x * 2048;
-    const u64 *s[NP];
-    u64 *d[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;
-        d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;
-    }
-    if (fp) p2_body<FpA, INV, NP, ST, SWZ, WGS>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
-    else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST, SWZ, WGS>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
-    else p2_body<IntA, INV, NP, ST, SWZ, WGS>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
+    P2_KERNEL_BODY(ST, P2_WGS_DEFAULT)
+}
+// the plain transform through round 4's workgroup-synchronous pass 2 (HYDIA_P2_WG_SYNC: parity variant) under its own name, so that the
+// instantiations of k_ntt15_p2 keep theirs in every profile
+template <bool INV, int NP>
+__global__ __launch_bounds__(256) void k_ntt15_p2_wgsync(NttTables T, const u64 *__restrict__ src, u64 *__restrict__ dst, size_t so, size_t dso, LimbSel sel,
+                                                          int slot0, int nsl, NttStore stp) {
+    P2_KERNEL_BODY(0, true)
 }
 
 // second pass of the ModUp forward NTTs fused with the key-switching inner product: grid (16, nlimbs*X), x fastest so the
@@ -1529,9 +1539,9 @@ static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t d
     if (ST == 5) sv.la.raw_fp = (stp.la.fp && stp.la.premul && !stp.dbl && !T.int_epilogue && T.twf != nullptr) ? 1 : 0;
     if (ST == 0 && T.p2_wg_sync) {  // parity variant of the plain transform: round 4's workgroup-synchronous pass 2
         if (pair_polys(X, nsl))
-            hipLaunchKernelGGL((k_ntt15_p2<false, 2, 0, true>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
+            hipLaunchKernelGGL((k_ntt15_p2_wgsync<false, 2>), dim3(16, (X / 2) * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
         else
-            hipLaunchKernelGGL((k_ntt15_p2<false, 1, 0, true>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
+            hipLaunchKernelGGL((k_ntt15_p2_wgsync<false, 1>), dim3(16, X * nsl), dim3(256), 0, st, T, dst, dst, dso, dso, sel, slot0, nsl, sv);
         return;
     }
     if (pair_polys(X, nsl))
@@ -1680,9 +1690,9 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
         ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * n * 262144.0);
         if (T.p2_wg_sync) {
             if (pair_polys(X, n))
-                hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0, true>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+                hipLaunchKernelGGL((k_ntt15_p2_wgsync<true, 2>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
             else
-                hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0, true>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+                hipLaunchKernelGGL((k_ntt15_p2_wgsync<true, 1>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
         } else if (pair_polys(X, n))
             hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
         else

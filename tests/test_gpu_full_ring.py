@@ -217,6 +217,53 @@ def test_config3_one_full_block_bit_exact_full_ring(im, full):
     assert np.array_equal(gmem.export()[0], mem.data()) and receiver.decryptMembership(gmem) is True
 
 
+def test_five_special_primes_below_2p48_full_ring(im):
+    """Round 5: a caller-supplied chain with FIVE special primes (here 47-bit ones: every limb but q_0 then runs on the FP64 pipe — the secondary
+    configuration of tools/exp_fp64_special_primes.py) goes through the FUSED pipeline: the ModDown conversions take the five-source
+    instantiation of the narrow column-fused kernel (k_ntt15_colfuse8<*, 5>).  Keys, query, similarity and index ciphertexts of a one-block
+    database equal the oracle's on the same chain, bit for bit; the answers are the planted matches."""
+    from sympy import isprime
+    base = O.Params()
+    M = 2 << 15
+    c, p5 = (1 << 47) - ((1 << 47) % M) + 1, []
+    while len(p5) < 5:
+        c -= M
+        if isprime(c):
+            p5.append(c)
+    moduli = np.array([int(x) for x in base.moduli[:base.nQ]] + p5, dtype=np.uint64)
+    base.close()
+    P = O.Params(moduli=moduli, n_p=5)
+    assert P.nP == 5 and P.dnum == 3
+    K = O.Keys(P, 31)
+    Or = O.Oracle(P, K)
+    cc = im.Context(im.default_params(), 0, moduli=moduli, roots=P.roots, n_p=5)
+    assert np.array_equal(cc.moduli, P.moduli) and cc.nP == 5
+    cc.keygen(31)
+    assert np.array_equal(cc.export_eval_key(0), K.relin()) and np.array_equal(cc.export_eval_key(1), K.rot_key(1))
+    n = 3000
+    rng = np.random.default_rng(15)
+    db = rng.integers(-99, 100, size=(n, 512)).astype(np.float64)
+    planted = [7, n - 1]
+    for i in planted:
+        db[i] = rng.integers(1, 4, size=512)
+    query = np.ones(512)
+    for matvec in ("hoisted", None):  # the reference's form (511 hoisted rotations: loop A's five-source ModDown) and the auto split
+        dbc = Or.enroll(db.copy(), 8, **({"matvec": matvec} if matvec else {}))
+        cc.set_matvec(matvec or "auto")
+        im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=8)
+        q = Or.encrypt_query(query, 2, 9)
+        receiver, sender = im.DiagonalReceiver(cc, n), im.DiagonalSender(cc, n)
+        gq = receiver.encryptQuery(query, seed=2, nonce=9)
+        assert np.array_equal(gq.export()[0], q.data())
+        sim, gsim = Or.compute_similarity(q, dbc, n), sender.computeSimilarity(gq)
+        assert np.array_equal(gsim.export()[0], sim[0].data()), matvec
+        idx, gidx = Or.index_scenario(q, dbc, n), sender.indexScenario(gq)
+        assert np.array_equal(gidx.export()[0], idx[0].data()), matvec
+        assert receiver.decryptIndex(gidx) == planted
+    cc.set_matvec("auto")
+    cc.close()
+
+
 def test_gpu_comparator_reproduces_published_transfer_curve(im, full):
     """(iii) chebyshevCompare(0.44, 10) on the GPU, decrypted, against the reference's own published output."""
     P, K, Or, cc = full

@@ -20,13 +20,13 @@ sys.path.insert(0, ROOT)
 import image_matching_amd as im  # noqa: E402
 
 
-def fp64_chain():
+def fp64_chain(count=4):
     d, mod, _ = im.describe_params(im.default_params())
     nq = d["n_q"]
     M = 2 << 15
     c = (1 << 47) - ((1 << 47) % M) + 1
     p = []
-    while len(p) < 4:
+    while len(p) < count:
         c -= M
         if isprime(c):
             p.append(c)
@@ -74,6 +74,15 @@ def check(cc, n=16384, dim=512):
 def main():
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     Q = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    if len(sys.argv) > 3 and sys.argv[3] == "5x47":  # dnum 3 with FIVE 47-bit special primes (235 bits >= the 195-bit first digit)
+        moduli, nq = fp64_chain(5)
+        cc = im.Context(im.default_params(), 0, moduli=moduli, n_p=5)
+        print("five 47-bit special primes, dnum 3: check at 2^14:", check(cc), flush=True)
+        cc.close()
+        cc = im.Context(im.default_params(), 0, moduli=moduli, n_p=5)
+        print("five 47-bit special primes, dnum 3: 2^%d: %.3f ms per query" % (L, timed(cc, 1 << L, Q)), flush=True)
+        cc.close()
+        return
     moduli, nq = fp64_chain()
     out = {"log2n": L, "queries": Q, "special_primes_fp64": [int(x) for x in moduli[nq:]], "dnum_fp64": 4}
     for name in ("reference chain (dnum 3, P = 4 x 60 bit)", "FP64 special primes (dnum 4, P = 4 x 47 bit)"):

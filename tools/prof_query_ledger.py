@@ -18,7 +18,12 @@ log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 what = sys.argv[3] if len(sys.argv) > 3 else "indexScenario"
 n = 1 << log2n
-cc = im.Context()
+if os.environ.get("HYDIA_EXP_CHAIN") == "5x47":  # the secondary configuration of tools/exp_fp64_special_primes.py: five 47-bit special primes, dnum 3
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from exp_fp64_special_primes import fp64_chain
+    cc = im.Context(im.default_params(), 0, moduli=fp64_chain(5)[0], n_p=5)
+else:
+    cc = im.Context()
 cc.fill_eval_keys_random(1)
 cc.db_fill_random(n, 2)
 rng = np.random.default_rng(0)
