@@ -369,6 +369,7 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
         tabs.generic = getenv("HYDIA_NTT_GENERIC") ? 1 : 0;
         tabs.cf_wide = getenv("HYDIA_COLFUSE_WIDE") ? 1 : 0;
         tabs.p2_wg_sync = getenv("HYDIA_P2_WG_SYNC") ? 1 : 0;
+        tabs.no_tw_lds = getenv("HYDIA_NO_TW_LDS") ? 1 : 0;
     }
     modup_per_digit = getenv("HYDIA_MODUP_PER_DIGIT") != nullptr;
     loop_a_separate_ip = getenv("HYDIA_LOOPA_SEPARATE_IP") != nullptr;

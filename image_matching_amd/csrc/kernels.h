@@ -29,6 +29,7 @@ struct NttTables {
     int ip_group;                  // HYDIA_IP_GROUP: ciphertexts per interleaving group of the merged inner-product kernel (default 8)
     int int_epilogue;              // HYDIA_INT_EPILOGUE: merged ModDown + Rescale epilogue in integers for every limb (round 3's form)
     int no_drop_in_ip;             // HYDIA_NO_DROP_IN_IP: the dropped limb's inverse pass 2 as its own launch (round 3's form)
+    int no_tw_lds;                 // HYDIA_NO_TW_LDS: pass 2's phase A / B twiddles of the FP64 limbs as per-lane vector loads (round 4's form) instead of a wave-local LDS table
     int p2_wg_sync;                // HYDIA_P2_WG_SYNC: the plain N = 2^15 transforms through round 4's workgroup-synchronous pass 2 (parity variant)
     int cf_wide;                   // HYDIA_COLFUSE_WIDE: round 4's column-fused kernel (32-column tiles, 16 rows per lane, two workgroups per CU)
     int generic;                   // HYDIA_NTT_GENERIC: the ring-size-generic transform kernels also at N = 2^15 (parity variant)

@@ -658,9 +658,78 @@ DEV void p2_sync() {
 template <bool WGS>
 DEV int p2_elem(int t, int hh) { return WGS ? 4 * t + 1024 * hh : (t >> 5) * 256 + 4 * (t & 31) + 128 * hh; }
 
+// Round 5: the twiddles of pass 2's phases A / B (and B' / A') of an FP64 limb come from a WAVE-LOCAL LDS table instead of fourteen 16-byte
+// vector loads per lane that fetch 2 (phase A) or 16 (phase B) distinct entries per wave.  The texture addresser spends its 16 cycles on
+// every such load whatever the lanes share, and it is what the pass-2 kernels are short of (TA_BUSY 0.67 - 0.79 of the duration in the
+// epilogue kernels, profiles/r05/query_counters_q20.txt): twiddle loads were ~55 % of a plain transform's vector-memory cycles.  A wave's two
+// blocks bg0, bg0 + 1 need one contiguous run of the table per stage — tw[128 + bg0 ..+2), [256 + 2 bg0 ..+4), [512 + 4 bg0 ..+8),
+// [1024 + 8 bg0 ..+16), [2048 + 16 bg0 ..+32), [4096 + 32 bg0 ..+64) — 126 entries at offsets 0, 2, 6, 14, 30, 62 of the wave's table,
+// fetched with TWO coalesced 8-byte loads per lane from the twiddles-alone table (NttTables::twd / itwd; w / q is formed as w (1/q),
+// FpA::tw8: an exact representative either way, same residues) — 1 KiB of LDS per wave, so no kernel loses a workgroup per CU.
+// tools/ubench/p2_swap.hip, fifth form: 5.39 against 4.81 TB/s for a plain FP64 pass 2 in the streaming regime.  The 60-bit limbs (16-byte
+// entries: a table would cost a workgroup per CU) and the workgroup-synchronous parity variant load as before.  HYDIA_NO_TW_LDS=1: off.
+struct P2Tab {
+    const double *g;  // the limb's twiddles-alone table in global memory, or null: no table
+    double *l;        // the workgroup's [4][128] doubles in LDS
+};
+DEV void p2_stage_twiddles(const double *__restrict__ g, double *wt, int bg0, int lane) {
+    double st[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int i = lane + 64 * r;
+        const int src = i < 2 ? 128 + bg0 + i : i < 6 ? 256 + 2 * bg0 + (i - 2) : i < 14 ? 512 + 4 * bg0 + (i - 6) :
+                        i < 30 ? 1024 + 8 * bg0 + (i - 14) : i < 62 ? 2048 + 16 * bg0 + (i - 30) : 4096 + 32 * bg0 + (i - 62);
+        st[r] = g[i < 126 ? src : 128 + bg0];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) wt[lane + 64 * r] = st[r];
+}
+// the seven twiddles of phase A / A' (block hb of the wave) and of phase B / B' (row group ibw = 8 hb + a of the wave)
+template <class A>
+DEV void p2_tw_A(const A &, const ulonglong2 *__restrict__ tw, const double *, int bg, int, typename A::TW &W7, typename A::TW &W8a, typename A::TW &W8b,
+                 typename A::TW (&W9)[4]) {
+    W7 = A::tw(tw[128 + bg]);
+    W8a = A::tw(tw[256 + 2 * bg]);
+    W8b = A::tw(tw[256 + 2 * bg + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
+}
+DEV void p2_tw_A(const FpA &ar, const ulonglong2 *__restrict__ tw, const double *wt, int bg, int hb, FpA::TW &W7, FpA::TW &W8a, FpA::TW &W8b, FpA::TW (&W9)[4]) {
+    if (wt) {
+        W7 = ar.tw8(wt[hb]);
+        W8a = ar.tw8(wt[2 + 2 * hb]);
+        W8b = ar.tw8(wt[2 + 2 * hb + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) W9[i] = ar.tw8(wt[6 + 4 * hb + i]);
+        return;
+    }
+    p2_tw_A<FpA>(ar, tw, nullptr, bg, hb, W7, W8a, W8b, W9);
+}
+template <class A>
+DEV void p2_tw_B(const A &, const ulonglong2 *__restrict__ tw, const double *, int ib, int, typename A::TW &W10, typename A::TW &W11a, typename A::TW &W11b,
+                 typename A::TW (&W12)[4]) {
+    W10 = A::tw(tw[1024 + ib]);
+    W11a = A::tw(tw[2048 + 2 * ib]);
+    W11b = A::tw(tw[2048 + 2 * ib + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
+}
+DEV void p2_tw_B(const FpA &ar, const ulonglong2 *__restrict__ tw, const double *wt, int ib, int ibw, FpA::TW &W10, FpA::TW &W11a, FpA::TW &W11b, FpA::TW (&W12)[4]) {
+    if (wt) {
+        W10 = ar.tw8(wt[14 + ibw]);
+        W11a = ar.tw8(wt[30 + 2 * ibw]);
+        W11b = ar.tw8(wt[30 + 2 * ibw + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) W12[i] = ar.tw8(wt[62 + 4 * ibw + i]);
+        return;
+    }
+    p2_tw_B<FpA>(ar, tw, nullptr, ib, ibw, W10, W11a, W11b, W12);
+}
+
 // phases B' and A' of the inverse second pass for NPI polynomials whose phase-C' output sits in lds (caller synchronised)
 template <class A, int NPI, bool SWZ = false, bool WGS = P2_WGS_DEFAULT>
-DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[P2Lds<SWZ>::SIZE], u64 *const *d, int t, int B0) {
+DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds)[P2Lds<SWZ>::SIZE], u64 *const *d, int t, int B0,
+                       const double *wt = nullptr /* the wave's staged table of THIS direction's twiddles (FP64 limbs), or null */) {
     typedef typename A::T T;
     typedef typename A::TW TW;
     typedef P2Lds<SWZ> LI;
@@ -672,11 +741,8 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
     // phase B': strides 4, 8, 16
     {
         const int ib = 8 * bg + a;
-        const TW W10 = A::tw(tw[1024 + ib]);
-        const TW W11a = A::tw(tw[2048 + 2 * ib]), W11b = A::tw(tw[2048 + 2 * ib + 1]);
-        TW W12[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
+        TW W10, W11a, W11b, W12[4];
+        p2_tw_B(ar, tw, wt, ib, 8 * (blk & 1) + a, W10, W11a, W11b, W12);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -699,11 +765,8 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
     p2_sync<WGS>();
     // phase A': strides 32, 64, 128
     {
-        const TW W7 = A::tw(tw[128 + bg]);
-        const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
-        TW W9[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
+        TW W7, W8a, W8b, W9[4];
+        p2_tw_A(ar, tw, wt, bg, blk & 1, W7, W8a, W8b, W9);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -734,13 +797,20 @@ DEV void p2_inverse_BA(const A &ar, const ulonglong2 *__restrict__ tw, u64 (*lds
 template <class A, bool INV, int NP, int ST, bool SWZ = false, bool WGS = P2_WGS_DEFAULT>
 DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const *s, u64 *const *d, u64 (*lds)[P2Lds<SWZ>::SIZE], int t,
                  int B0, const NttStore &stp, const ModC &M, int xp0, int slot, const ulonglong2 *__restrict__ itw = nullptr,
-                 u64 *const *dinv = nullptr) {
+                 u64 *const *dinv = nullptr, const P2Tab tab = P2Tab{nullptr, nullptr}) {
     typedef typename A::T T;
     typedef typename A::TW TW;
     typedef P2Lds<SWZ> LI;
     const int blk = t >> 5, w = t & 31;
     const int bg = (B0 >> 8) + blk;
     const int a = w >> 2, b = w & 3;
+    // FP64 limbs: the wave's table of phase A / B twiddles (requested FIRST: the loads return in order, and the table is wanted before the data)
+    const double *wt = nullptr;
+    if (std::is_same<A, FpA>::value && !WGS && tab.g && tab.l) {
+        double *wl = tab.l + (t >> 6) * 128;
+        p2_stage_twiddles(tab.g, wl, (B0 >> 8) + 2 * (t >> 6), t & 63);
+        wt = wl;
+    }
     T v[NP][8];
     if (!INV) {
         // phase A: coefficients blk*256 + 32k + w ; stages 7,8,9 (strides 128, 64, 32)
@@ -749,11 +819,9 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
 #pragma unroll
             for (int k = 0; k < 8; k++) v[p][k] = ar.from_raw(s[p][blk * 256 + 32 * k + w]);  // raw from pass 1
         {
-            const TW W7 = A::tw(tw[128 + bg]);
-            const TW W8a = A::tw(tw[256 + 2 * bg]), W8b = A::tw(tw[256 + 2 * bg + 1]);
-            TW W9[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) W9[i] = A::tw(tw[512 + 4 * bg + i]);
+            if (wt) p2_sync<false>();  // the table is in place (a wave's own writes, in order)
+            TW W7, W8a, W8b, W9[4];
+            p2_tw_A(ar, tw, wt, bg, blk & 1, W7, W8a, W8b, W9);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -775,11 +843,8 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         // phase B: coefficients blk*256 + 32a + 4k + b ; stages 10,11,12 (strides 16, 8, 4)
         {
             const int ib = 8 * bg + a;
-            const TW W10 = A::tw(tw[1024 + ib]);
-            const TW W11a = A::tw(tw[2048 + 2 * ib]), W11b = A::tw(tw[2048 + 2 * ib + 1]);
-            TW W12[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) W12[i] = A::tw(tw[4096 + 4 * ib + i]);
+            TW W10, W11a, W11b, W12[4];
+            p2_tw_B(ar, tw, wt, ib, 8 * (blk & 1) + a, W10, W11a, W11b, W12);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -988,7 +1053,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
             }
         }
         p2_sync<WGS>();
-        p2_inverse_BA<A, NP, SWZ, WGS>(ar, tw, lds, d, t, B0);
+        p2_inverse_BA<A, NP, SWZ, WGS>(ar, tw, lds, d, t, B0, wt);
     }
 }
 
@@ -1005,6 +1070,7 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
     constexpr int N = 32768;                                                                                                              \
     constexpr bool SWZ = false;                                                                                                           \
     __shared__ u64 lds[NP][P2Lds<SWZ>::SIZE];                                                                                             \
+    __shared__ double twl[4][128];                                                                                                        \
     const int y = blockIdx.y;                                                                                                             \
     const bool rot_fastest = !INV && ST_ == 5 && !stp.la.limb_fastest;                                                                    \
     const int nxp = gridDim.y / nsl;                                                                                                      \
@@ -1019,7 +1085,9 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
         s[p] = src + (size_t)(xp * NP + p) * so + (size_t)slot * N + B0;                                                                  \
         d[p] = dst + (size_t)(xp * NP + p) * dso + (size_t)slot * N + B0;                                                                 \
     }                                                                                                                                     \
-    if (fp) p2_body<FpA, INV, NP, ST_, SWZ, WGS_>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);                         \
+    const double *const twg = (INV ? T.itwd : T.twd);                                                                                      \
+    const P2Tab tab{(fp && twg && !T.no_tw_lds) ? twg + (size_t)m * N : nullptr, &twl[0][0]};                                              \
+    if (fp) p2_body<FpA, INV, NP, ST_, SWZ, WGS_>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot, nullptr, nullptr, tab);   \
     else if ((T.pm_mask >> m) & 1u) p2_body<IntP, INV, NP, ST_, SWZ, WGS_>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot); \
     else p2_body<IntA, INV, NP, ST_, SWZ, WGS_>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, xp * NP, slot);
 template <bool INV, int NP, int ST>
@@ -1041,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_ntt15_p2_wgsync(NttTables T, const u64 
 // workgroups that share a key tile follow each other.  Limb t = t0 + slot; the NP digits are all digits but the limb's own.
 template <int NP, bool OWN, bool TAIL, bool SWZ = false>
 DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t dxs, int t, int x, const NttStore &stp, int bx,
-                         u64 (*lds)[P2Lds<SWZ>::SIZE]) {
+                         u64 (*lds)[P2Lds<SWZ>::SIZE], double *twl) {
     constexpr int N = 32768;
     const int m = t < stp.ip.nl ? t : stp.ip.nT - stp.ip.nE + t;
     const ModC M = T.mod[m];
@@ -1063,20 +1131,21 @@ DEV void p2_ip_workgroup(const NttTables &T, const u64 *__restrict__ dig, size_t
 #pragma unroll
         for (int pp = 0; pp < 2; pp++)
             dinv[pp] = stp.ip.inv_out + (size_t)(2 * x + pp) * stp.ip.inv_outer + (size_t)(stp.ip.inv_row0 + t - stp.ip.nl) * N + B0;
-        if (fp) p2_body<FpA, false, NP, 6, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
+        if (fp) p2_body<FpA, false, NP, 6, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv, P2Tab{(T.twd && !T.no_tw_lds) ? T.twd + (size_t)m * N : nullptr, twl});
         else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 6, SWZ>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
         else p2_body<IntA, false, NP, 6, SWZ>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, itw, dinv);
         return;
     }
-    if (fp) p2_body<FpA, false, NP, 4, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
+    if (fp) p2_body<FpA, false, NP, 4, SWZ>(FpA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t, nullptr, nullptr, P2Tab{(T.twd && !T.no_tw_lds) ? T.twd + (size_t)m * N : nullptr, twl});
     else if ((T.pm_mask >> m) & 1u) p2_body<IntP, false, NP, 4, SWZ>(IntP(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
     else p2_body<IntA, false, NP, 4, SWZ>(IntA(M), tw, s, d, lds, threadIdx.x, B0, stp, M, x, t);
 }
 template <int NP, bool OWN, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_ntt15_p2_ip(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int t0, NttStore stp) {
     __shared__ u64 lds[(TAIL && NP < 2) ? 2 : NP][8 * 288];
+    __shared__ double twl[4][128];
     const int slot = blockIdx.y / X, x = blockIdx.y - slot * X;  // x fastest: the workgroups that share a key tile follow each other
-    p2_ip_workgroup<NP, OWN, TAIL>(T, dig, dxs, t0 + slot, x, stp, blockIdx.x, lds);
+    p2_ip_workgroup<NP, OWN, TAIL>(T, dig, dxs, t0 + slot, x, stp, blockIdx.x, lds, &twl[0][0]);
 }
 // both halves of a relinearisation's fused inner product in ONE launch: the Q limbs (ND - 1 digits transformed, the limb's own digit
 // read in place; FP64, HBM-bound) and the special-prime limbs with the inverse tail (ND digits; 60-bit integer, ALU-bound).  Rows of
@@ -1088,13 +1157,14 @@ template <int ND>
 __global__ __launch_bounds__(256, ND == 2 ? 4 : 1) void k_ntt15_p2_ip_all(NttTables T, const u64 *__restrict__ dig, size_t dxs, int X, int xb, NttStore stp) {
     constexpr bool SWZ = ND >= 3;  // three (or four) images: the unpadded, XOR-swizzled form buys a workgroup per CU (P2Lds)
     __shared__ u64 lds[ND][P2Lds<SWZ>::SIZE];
+    __shared__ double twl[4][128];
     const int nl = stp.ip.nl, nS = stp.ip.nE, nP = nS - nl;
     const int per = nS * xb, grp = blockIdx.y / per, r = blockIdx.y - grp * per;
     const int si = r / xb, x = grp * xb + (r - si * xb);
     const int pc = si * nP / nS, pc1 = (si + 1) * nP / nS;
-    if (pc1 > pc) p2_ip_workgroup<ND, false, true, SWZ>(T, dig, dxs, nl + pc, x, stp, blockIdx.x, lds);
-    else if (si - pc == stp.ip.drop_l) p2_ip_workgroup<ND - 1, true, true, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);  // (ND >= 2 images: enough for the tail)
-    else p2_ip_workgroup<ND - 1, true, false, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds);
+    if (pc1 > pc) p2_ip_workgroup<ND, false, true, SWZ>(T, dig, dxs, nl + pc, x, stp, blockIdx.x, lds, &twl[0][0]);
+    else if (si - pc == stp.ip.drop_l) p2_ip_workgroup<ND - 1, true, true, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds, &twl[0][0]);  // (ND >= 2 images: enough for the tail)
+    else p2_ip_workgroup<ND - 1, true, false, SWZ>(T, dig, dxs, si - pc, x, stp, blockIdx.x, lds, &twl[0][0]);
 }
 
 
@@ -1522,7 +1592,13 @@ static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u6
 }
 // two polynomials per workgroup share the twiddle loads.  Small launches (below 4 workgroups per CU when paired — the per-query
 // fixed-cost tail) run one polynomial per workgroup: twice the workgroups, half the serial work in each
-static bool pair_polys(int X, int nsl) { return X % 2 == 0 && (X / 2) * nsl * 16 >= 1024; }
+static bool pair_polys(int X, int nsl) {
+    static const int mode = [] {  // experiment knob HYDIA_P2_PAIR: 0 = never pair (one polynomial per workgroup: more waves per SIMD), default = pair large launches
+        const char *e = getenv("HYDIA_P2_PAIR");
+        return e ? atoi(e) : 1;
+    }();
+    return mode != 0 && X % 2 == 0 && (X / 2) * nsl * 16 >= 1024;
+}
 template <int ST>
 static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl,
                           const NttStore &stp) {

@@ -122,6 +122,53 @@ DEV void phase_b(const A &ar, const TwB<A> &W, typename A::T (&v)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; k += 2) ar.ct(v[k], v[k + 1], W.W12[k >> 1]);
 }
+// Twiddles of phases A and B from a WAVE-LOCAL LDS table (variant 3).  A wave's two blocks bg0, bg0 + 1 need, per stage, a contiguous run of
+// the table: tw[128 + bg0 ..+2), tw[256 + 2 bg0 ..+4), tw[512 + 4 bg0 ..+8), tw[1024 + 8 bg0 ..+16), tw[2048 + 16 bg0 ..+32), tw[4096 + 32 bg0 ..+64)
+// = 126 entries at offsets 0, 2, 6, 14, 30, 62: two 16-byte global loads per lane, coalesced, instead of fourteen per lane that fetch
+// 2 (phase A) or 16 (phase B) distinct entries per wave — the texture addresser spends 16 cycles on every one of them whatever the lanes share.
+DEV void stage_twiddles(const ulonglong2 *__restrict__ tw, ulonglong2 *tab, int bg0, int lane) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int i = lane + 64 * r;  // entry of the wave's table
+        int src;
+        if (i < 2) src = 128 + bg0 + i;
+        else if (i < 6) src = 256 + 2 * bg0 + (i - 2);
+        else if (i < 14) src = 512 + 4 * bg0 + (i - 6);
+        else if (i < 30) src = 1024 + 8 * bg0 + (i - 14);
+        else if (i < 62) src = 2048 + 16 * bg0 + (i - 30);
+        else src = 4096 + 32 * bg0 + (i - 62);
+        if (i < 126) tab[i] = tw[src];
+    }
+}
+template <class A>
+DEV void phase_a_lds(const A &ar, const ulonglong2 *tab, typename A::T (&v)[8], int hb /* block of the wave: 0 / 1 */) {
+    typedef typename A::TW TW;
+    const TW W7 = A::tw(tab[hb]);
+    const TW W8a = A::tw(tab[2 + 2 * hb]), W8b = A::tw(tab[2 + 2 * hb + 1]);
+    TW W9[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) W9[i] = A::tw(tab[6 + 4 * hb + i]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ar.ct(v[k], v[k + 4], W7);
+    ar.ct(v[0], v[2], W8a);
+    ar.ct(v[1], v[3], W8a);
+    ar.ct(v[4], v[6], W8b);
+    ar.ct(v[5], v[7], W8b);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) ar.ct(v[k], v[k + 1], W9[k >> 1]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ar.fwd_fold(v[k]);
+}
+template <class A>
+DEV void load_twb_lds(TwB<A> &W, const ulonglong2 *tab, int hb, int a) {
+    const int ib = 8 * hb + a;  // 0 .. 15 inside the wave
+    W.W10 = A::tw(tab[14 + ib]);
+    W.W11a = A::tw(tab[30 + 2 * ib]);
+    W.W11b = A::tw(tab[30 + 2 * ib + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) W.W12[i] = A::tw(tab[62 + 4 * ib + i]);
+}
+
 // four consecutive coefficients e .. e+3 of the chunk at d (global index B0 + e)
 template <class A>
 DEV void phase_c(const A &ar, const ulonglong2 *__restrict__ tw, typename A::T c0, typename A::T c1, typename A::T c2, typename A::T c3,
@@ -144,6 +191,7 @@ __global__ __launch_bounds__(256) void k_p2(const ulonglong2 *__restrict__ tw, M
     constexpr int NP = 2, N = 32768;
     typedef typename A::T T;
     __shared__ u64 lds[VAR == 2 ? 1 : NP][VAR == 2 ? 1 : IMG];
+    __shared__ ulonglong2 twtab[VAR == 3 ? 4 : 1][128];
     const A ar(M);
     const int t = threadIdx.x, blk = t >> 5, w = t & 31, B0 = blockIdx.x * 2048, bg = (B0 >> 8) + blk;
     const int a = w >> 2, b = w & 3;
@@ -161,10 +209,19 @@ __global__ __launch_bounds__(256) void k_p2(const ulonglong2 *__restrict__ tw, M
         for (int p = 0; p < NP; p++)
 #pragma unroll
             for (int k = 0; k < 8; k++) v[p][k] = ar.from_raw(s[p][blk * 256 + 32 * k + w]);
-#pragma unroll
-        for (int p = 0; p < NP; p++) phase_a(ar, tw, v[p], bg);
         TwB<A> WB;
-        WB.load(tw, 8 * bg + a);
+        if (VAR == 3) {
+            ulonglong2 *tab = twtab[t >> 6];
+            stage_twiddles(tw, tab, (B0 >> 8) + 2 * (t >> 6), t & 63);
+            wave_sync();
+#pragma unroll
+            for (int p = 0; p < NP; p++) phase_a_lds(ar, tab, v[p], blk & 1);
+            load_twb_lds(WB, tab, blk & 1, a);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; p++) phase_a(ar, tw, v[p], bg);
+            WB.load(tw, 8 * bg + a);
+        }
         if (VAR == 2) {
 #pragma unroll
             for (int p = 0; p < NP; p++) {
@@ -331,7 +388,7 @@ int main() {
     CK(hipMalloc((void **)&d_src, n * 8));
     CK(hipMalloc((void **)&d_dst, n * 8));
     std::vector<u64> h(n), ref((size_t)polys_l2 * N), out((size_t)polys_l2 * N);
-    const char *names[3] = {"wg-lds   (round 4)", "wave-lds (no barrier)", "wave-swap (no LDS)"};
+    const char *names[4] = {"wg-lds   (round 4)", "wave-lds (no barrier)", "wave-swap (no LDS)", "wave-lds + LDS twiddles"};
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const double clk = prop.clockRate * 1e3, cus = prop.multiProcessorCount;
@@ -346,14 +403,14 @@ int main() {
         }
         CK(hipMemcpy(d_src, h.data(), n * 8, hipMemcpyHostToDevice));
         printf("%s\n", arith == 0 ? "FpA (45-bit prime, FP64 butterflies)" : "IntP (2^60 - c, lazy integer butterflies)");
-        for (int var = 0; var < 3; var++) {
+        for (int var = 0; var < 4; var++) {
             CK(hipMemset(d_dst, 0, n * 8));
             float l2 = 0, hbm = 0;
             const ulonglong2 *tw = arith == 0 ? d_twf : d_twp;
             const ModC &M = arith == 0 ? Mf : Mi;
 #define RUN(AR, V) { l2 = run<AR, V>(tw, M, d_src, d_dst, polys_l2, 64, 5); hbm = run<AR, V>(tw, M, d_src, d_dst, polys_hbm, 1, 10); }
-            if (arith == 0) { if (var == 0) RUN(FpA, 0) else if (var == 1) RUN(FpA, 1) else RUN(FpA, 2) }
-            else { if (var == 0) RUN(IntP, 0) else if (var == 1) RUN(IntP, 1) else RUN(IntP, 2) }
+            if (arith == 0) { if (var == 0) RUN(FpA, 0) else if (var == 1) RUN(FpA, 1) else if (var == 2) RUN(FpA, 2) else RUN(FpA, 3) }
+            else { if (var == 0) RUN(IntP, 0) else if (var == 1) RUN(IntP, 1) else if (var == 2) RUN(IntP, 2) else RUN(IntP, 3) }
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(out.data(), d_dst, out.size() * 8, hipMemcpyDeviceToHost));
             if (var == 0) ref = out;
