@@ -177,18 +177,22 @@ def git_head():
         return ""
 
 
-def stream_ceiling():
-    """what this GPU gives a read-once sequential stream in loop B's own access pattern (tools/ubench/stream_rate.hip): the
-    "workgroup-sequential layout" figure of the newest committed profiles/r*/stream_rate.txt -> (GB/s, file), or (None, None)"""
+def stream_ceiling(bits46=True):
+    """what this GPU gives a read-once sequential stream in loop B's own access pattern (tools/ubench/stream_rate.hip), from the newest
+    committed profiles/r*/stream_rate.txt: the 46-bit-unit figure for a 46-bit database ("... with 46-bit residues ...: X TB/s of distinct
+    bytes"), else the 48-bit "workgroup-sequential layout" one -> (GB/s, file), or (None, None)"""
     import glob
     import re
+    pats = ([r"with 46-bit residues[^\n]*?:\s*([0-9.]+) TB/s"] if bits46 else []) + [r"^\s*workgroup-sequential layout:\s*([0-9.]+) TB/s"]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "stream_rate.txt")), reverse=True):
         try:
-            m = re.search(r"^\s*workgroup-sequential layout:\s*([0-9.]+) TB/s", open(path).read(), re.M)
+            text = open(path).read()
         except OSError:
             continue
-        if m:
-            return float(m.group(1)) * 1e3, os.path.relpath(path, ROOT)
+        for pat in pats:
+            m = re.search(pat, text, re.M)
+            if m:
+                return float(m.group(1)) * 1e3, os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -633,8 +637,8 @@ def main():
                          "traffic": traffic, "traffic_rate": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
                          "traffic_meta": traffic_meta,
                          "algorithmic_frac": achieved / HBM_PEAK_GBS, "algorithmic_achieved": achieved, "algorithmic_bytes_per_launch": algo_bytes,
-                         "vs_measured_stream_ceiling": (wire / stream_ceiling()[0]) if stream_ceiling()[0] else None,
-                         "stream_ceiling": {"GBs": stream_ceiling()[0], "source": stream_ceiling()[1]},
+                         "vs_measured_stream_ceiling": (wire / stream_ceiling(db_bits_timed == 46)[0]) if stream_ceiling(db_bits_timed == 46)[0] else None,
+                         "stream_ceiling": {"GBs": stream_ceiling(db_bits_timed == 46)[0], "source": stream_ceiling(db_bits_timed == 46)[1]},
                          "step": step_roofline,
                          "note": "achieved/frac = bytes RESIDENT in HBM that one loop-B pass has to move (database with 46- or 48-bit residues for the "
                                  "45/46-bit limbs, see config.workload, + rotated queries + accumulators at 8 bytes: every byte once) / mean pass duration (HIP events on "

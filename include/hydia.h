@@ -74,7 +74,9 @@ int hydia_ctx_create(const hydia_params *p, int device, hydia_ctx **out);
  * (GetParamsP()), and optionally the 2N-th roots OpenFHE uses (GetRootOfUnity()) so evaluation-form data can cross the
  * boundary unconverted.  n_q = mult_depth + 1.  Every modulus must be a distinct prime < 2^60 that is 1 mod 2N; limbs
  * of at most 47 bits take the FP64 NTT path; limbs below 2^48 are stored packed in the database (46-bit residues in the
- * group-sequential layout when every limb but q_0 is below 2^46, 48-bit otherwise: hydia_db_residue_bits). */
+ * group-sequential layout when every limb but q_0 is below 2^46, 48-bit otherwise: hydia_db_residue_bits).
+ * The fused key-switching pipeline (column-fused conversions) serves up to four special primes of any width — OpenFHE's choice for the
+ * reference's parameter set — or five below 2^48; other counts run the same arithmetic through the unfused kernels (bit-identical, slower). */
 int hydia_ctx_create_custom(const hydia_params *p, const uint64_t *moduli, const uint64_t *roots /* may be NULL */,
                             uint32_t n_q, uint32_t n_p, int device, hydia_ctx **out);
 void hydia_ctx_destroy(hydia_ctx *ctx);

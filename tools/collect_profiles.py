@@ -51,6 +51,9 @@ cp("latency.csv", "cli_latency.csv")
 cp("pytest_gpu_final.log", "pytest_gpu_%s.log" % tag)
 cp("bench_forcedist.json", "bench_one_rank_rccl_%s.json" % tag)
 cp("bench_rehearse2.json", "bench_two_ranks_gloo_one_gpu_%s.json" % tag)
+cp("query_pmc_q20.txt", "query_pmc_q20_%s.txt" % tag)       # round 5: PMC bytes of every kernel of a 2^20 query / of loop A beside the ledger
+cp("loop_a_pmc.txt", "loop_a_pmc_%s.txt" % tag)
+cp("kernel_rooflines_q20_two_lanes.txt", "kernel_rooflines_q20_two_lanes_%s.txt" % tag)
 
 
 def per_pass(path):
@@ -77,3 +80,15 @@ out = {
 }
 json.dump(out, open(os.path.join(R, "profiles", "tensor_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# round 5: the one-GPU components bench.py --gpus N turns into DESIGN section 7's prediction (profiles/scaling_model.json)
+try:
+    mp = os.path.join(R, "profiles", "scaling_model.json")
+    model = json.load(open(mp))
+    for lg in (20, 17):
+        model["log2n"][str(lg)] = json.load(open(os.path.join(G, "scaling_components_%d.json" % lg)))["ranks"]
+    model["source"] = "profiles/%s/scaling_components_2p20_%s.json, scaling_components_2p17_%s.json" % (ROUND, tag, tag)
+    json.dump(model, open(mp, "w"), indent=1)
+    print("scaling_model.json refreshed from", model["source"])
+except (OSError, KeyError) as e:
+    print("scaling_model.json not refreshed:", e)
