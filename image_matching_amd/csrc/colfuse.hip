@@ -725,15 +725,9 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
 
 namespace hk {
 
-// launches below this many 32-column tiles take the small-launch form (pass 1' as its own launch + one target per workgroup).
-// HYDIA_CF_SMALL=<tiles> moves the crossover (0: never) — an experiment knob, read once per process
-bool ntt15_colfuse_small(int XP, int ncf) {
-    static const int lim = [] {
-        const char *e = getenv("HYDIA_CF_SMALL");
-        return e ? atoi(e) : 256;
-    }();
-    return 8 * XP * ncf < lim;
-}
+// launches below 256 32-column tiles take the small-launch form (pass 1' as its own launch + one target per workgroup; the crossover was
+// re-measured with the narrow kernel in round 5: nothing between 0 and 256 tiles leaves the run-to-run spread)
+bool ntt15_colfuse_small(int XP, int ncf) { return 8 * XP * ncf < 256; }
 
 void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
                    const ColFuse *h_cf, int ncf, bool pre) {

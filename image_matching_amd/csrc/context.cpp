@@ -280,7 +280,6 @@ Context::Context(const Params &p, int dev) : HostParams(p), device(dev) {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lane_stream.push_back(stream);
     if (const char *e = getenv("HYDIA_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
-    if (const char *e = getenv("HYDIA_LANE_SPLIT")) lane_split = atof(e);
     if (getenv("HYDIA_NO_PROD_FUSE")) prod_fuse = false;
     if (getenv("HYDIA_DB_48BIT")) db_bits46_ok = false;
     if (getenv("HYDIA_NO_CSUB_FUSE")) prod_fuse_csub = false;

@@ -1398,12 +1398,7 @@ Ct Context::relin_compare_lanes(Ct &acc, double dlt, int sign_depth) {
     std::vector<Ct> res(L);
     Ct out;
     for (int k = 0; k < L; k++) {
-        int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
-        if (L == 2 && lane_split > 0.0 && G >= 4) {  // experiment knob HYDIA_LANE_SPLIT: lane 0's share of the blocks (the lanes then drift out of step)
-            const int cut = std::max(1, std::min(G - 1, (int)(G * lane_split + 0.5)));
-            g0 = k == 0 ? 0 : cut;
-            g1 = k == 0 ? cut : G;
-        }
+        const int g0 = (int)((long)G * k / L), g1 = (int)((long)G * (k + 1) / L);
         set_lane(k);
         if (k > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev[L], 0));
         Ct part = acc.alias(acc.nl);

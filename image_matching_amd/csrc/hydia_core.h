@@ -111,7 +111,6 @@ struct Context : HostParams {
     hipStream_t stream = nullptr;  // the CURRENT lane's stream (lane 0 unless inside a multi-lane section)
     std::vector<hipStream_t> lane_stream;  // lane 0 = the main stream
     int nlanes = 2;                        // comparator lanes (HYDIA_LANES)
-    double lane_split = 0.0;               // HYDIA_LANE_SPLIT (experiment knob): lane 0's share of the blocks when there are two lanes; 0 = halves
     std::vector<hipEvent_t> lane_ev;
     void set_lane(int k);
     void sync_all();

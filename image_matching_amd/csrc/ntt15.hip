@@ -1592,13 +1592,7 @@ static void launch_p1_fwd(hipStream_t st, const NttTables &T, const u64 *src, u6
 }
 // two polynomials per workgroup share the twiddle loads.  Small launches (below 4 workgroups per CU when paired — the per-query
 // fixed-cost tail) run one polynomial per workgroup: twice the workgroups, half the serial work in each
-static bool pair_polys(int X, int nsl) {
-    static const int mode = [] {  // experiment knob HYDIA_P2_PAIR: 0 = never pair (one polynomial per workgroup: more waves per SIMD), default = pair large launches
-        const char *e = getenv("HYDIA_P2_PAIR");
-        return e ? atoi(e) : 1;
-    }();
-    return mode != 0 && X % 2 == 0 && (X / 2) * nsl * 16 >= 1024;
-}
+static bool pair_polys(int X, int nsl) { return X % 2 == 0 && (X / 2) * nsl * 16 >= 1024; }
 template <int ST>
 static void launch_p2_fwd(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl,
                           const NttStore &stp) {
