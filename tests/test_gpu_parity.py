@@ -410,6 +410,10 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         {"HYDIA_NTT_GENERIC": "1", "HYDIA_NO_COLFUSE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_NO_MERGE_RESCALE": "1"},
         # the unfused pipeline on the default arithmetics (FP64 + lazy pseudo-Mersenne butterflies through the plain epilogues)
         {"HYDIA_NO_MERGE_RESCALE": "1", "HYDIA_NO_FUSE_IP": "1", "HYDIA_NO_FUSE_LOOPA": "1", "HYDIA_KEYS_UNPACKED": "1"},  # Harvey [0, 4q) butterflies for the 60-bit primes; two inner-product launches
+        # round 5's changes back in round 4's forms: the wide column-fused conversions, per-lane twiddle loads in pass 2, loop A's last pass
+        # limbs-fastest, the plain transforms through the workgroup-synchronous pass 2
+        {"HYDIA_COLFUSE_WIDE": "1", "HYDIA_NO_TW_LDS": "1", "HYDIA_LOOPA_LIMB_FASTEST": "1", "HYDIA_P2_WG_SYNC": "1"},
+        {"HYDIA_NO_TW_LDS": "1"},
     ]
     n = 40000
     rng = np.random.default_rng(77)
@@ -421,7 +425,8 @@ def test_fast_paths_equal_plain_pipeline_full_ring(im, monkeypatch):
         for k in ("HYDIA_NTT_INT", "HYDIA_DB_UNPACKED", "HYDIA_KEYS_UNPACKED", "HYDIA_NO_MERGE_RESCALE", "HYDIA_NO_FUSE_IP", "HYDIA_LANES",
                   "HYDIA_NTT_1PASS", "HYDIA_NTT_1PASS_MIN", "HYDIA_NO_FORK", "HYDIA_NO_FUSE_LOOPA", "HYDIA_MODUP_PER_DIGIT",
                   "HYDIA_LOOPA_SEPARATE_IP", "HYDIA_RELIN_SEPARATE_INTT", "HYDIA_LOOPA_INT_IP", "HYDIA_NTT_NO_PM", "HYDIA_RELIN_TWO_IP_LAUNCHES",
-                  "HYDIA_NO_COLFUSE", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW", "HYDIA_IP_GROUP", "HYDIA_NTT_GENERIC", "HYDIA_NO_DROP_IN_IP", "HYDIA_INT_EPILOGUE", "HYDIA_NO_PROD_FUSE", "HYDIA_NO_KS_FUSE", "HYDIA_NO_RESCALE_CF", "HYDIA_NO_CSUB_FUSE"):
+                  "HYDIA_NO_COLFUSE", "HYDIA_TENSOR_BPP", "HYDIA_TENSOR_NW", "HYDIA_IP_GROUP", "HYDIA_NTT_GENERIC", "HYDIA_NO_DROP_IN_IP", "HYDIA_INT_EPILOGUE", "HYDIA_NO_PROD_FUSE", "HYDIA_NO_KS_FUSE", "HYDIA_NO_RESCALE_CF", "HYDIA_NO_CSUB_FUSE",
+                  "HYDIA_COLFUSE_WIDE", "HYDIA_NO_TW_LDS", "HYDIA_LOOPA_LIMB_FASTEST", "HYDIA_P2_WG_SYNC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
