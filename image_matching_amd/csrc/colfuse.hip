@@ -721,6 +721,121 @@ __global__ __launch_bounds__(256, MDR ? 2 : 4) void k_ntt15_conv_p1(NttTables T,
     }
 }
 
+// The small-launch form on 16-column tiles (round 5): a lane converts 8 rows instead of 16 and the column transform runs as cf_forward8 —
+// twice the workgroups, each with half the serial chain (the small launches are bound by one workgroup's chain, not by throughput).
+// HYDIA_COLFUSE_WIDE keeps the 32-column form above.  grid (16 column tiles, XP polynomials, ncf maps x targets)
+template <bool MDR>
+__global__ __launch_bounds__(256, 4) void k_ntt15_conv_p1_8(NttTables T, const u64 *__restrict__ src, size_t so, u64 *__restrict__ dst,
+                                                           size_t dso, const ColFuse *__restrict__ cfs, int nt_max) {
+    constexpr int N = 32768;
+    __shared__ u64 lds[CF8_IMG];
+    __shared__ ulonglong2 ltw[128];
+    const int zi = blockIdx.z / nt_max, tt = blockIdx.z - zi * nt_max;
+    const ColFuse &cf = cfs[zi];
+    if (tt >= cf.nt) return;  // workgroup-uniform
+    const int t = threadIdx.x, col = t & (CF8_COLS - 1), g = t >> 4;
+    const int xp = blockIdx.y, c0 = blockIdx.x * CF8_COLS;
+    const u64 *sb = src + (size_t)xp * so + c0 + col;
+    const int m = cf.tmod[tt];
+    const ModC M = cf.tM[tt];  // (off the map: no dependent load between the target's id and its constants)
+    const bool fp = (T.fp_mask >> m) & 1u;
+    const ulonglong2 *__restrict__ tw = (fp ? T.twf : T.twp) + (size_t)m * N;
+    if (t < 128) ltw[t] = tw[t];
+    CfConst f, fl;
+    const u64 *sp[HY_CF_SRC];
+#pragma unroll
+    for (int s = 0; s < HY_CF_SRC; s++) {
+        const bool on = s < cf.nk;
+        f.set(s, on ? cf.f[s][tt] : 0);
+        fl.set(s, (MDR && on) ? cf.fl[s] : 0);
+        sp[s] = sb + (size_t)cf.srow[on ? s : 0] * N;  // absent sources re-read source 0 against a zero constant
+    }
+    const u64 *su = MDR ? sb + (size_t)cf.urow * N : sb;
+    const ModC Ml = MDR ? cf.lM : M;
+    u64 *d = dst + (size_t)xp * dso + (size_t)cf.trow[tt] * N + c0;
+    // one row at a time: the (up to five) operands of row g + 16k are loaded where they are used; a holds sum_s y_s f_s, the dropped
+    // limb's centred residue (MDR) is formed from the same operands
+    auto convert_row = [&](int k, CfSum &a, u64 &mag, bool &ng) {
+        const size_t off = (size_t)(g + 16 * k) * 256;
+        const u64 y0 = cf_split30(sp[0][off]), y1 = cf_split30(sp[1][off]), y2 = cf_split30(sp[2][off]), y3 = cf_split30(sp[3][off]);
+        a = cf_mac4(y0, y1, y2, y3, f);
+        mag = 0;
+        ng = false;
+        if (MDR) {
+            const u64 yl = submod(su[off], reduce128k(cf_mac4(y0, y1, y2, y3, fl).wide(), Ml), Ml.q);
+            ng = yl > (Ml.q >> 1);
+            mag = ng ? Ml.q - yl : yl;
+        }
+    };
+    if (fp) {
+        const FpA ar(M);
+        const double c60 = FpA::u2d(cf.t60[tt]);
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            CfSum a;
+            u64 mag;
+            bool ng;
+            convert_row(k, a, mag, ng);
+            double r = cf_fold(ar, a, c60);
+            if (MDR) r += ng ? -FpA::u2d(mag) : FpA::u2d(mag);
+            v[k] = r;
+        }
+        cf_forward8<FpA>(ar, tw, ltw, lds, g, col, v, d);
+    } else {
+        const bool pm = (T.pm_mask >> m) & 1u;
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            CfSum a;
+            u64 mag;
+            bool ng;
+            convert_row(k, a, mag, ng);
+            u64 r;
+            if (pm) {  // folded, lazy (cf_convert's pseudo-Mersenne form)
+                r = IntP(M).fold_lh(a.L, a.H);
+                if (MDR) {
+                    const u64 c = reduce64(mag, M);
+                    r += ng ? M.q - c : c;
+                }
+            } else {
+                r = reduce128k(a.wide(), M);
+                if (MDR) {
+                    const u64 c = reduce64(mag, M);
+                    r = addmod(r, ng ? negmod(c, M.q) : c, M.q);
+                }
+            }
+            v[k] = r;
+        }
+        if (pm) cf_forward8<IntP>(IntP(M), tw, ltw, lds, g, col, v, d);
+        else cf_forward8<IntA>(IntA(M), tw, ltw, lds, g, col, v, d);
+    }
+}
+
+// inverse pass 1' ALONE on 16-column tiles (round 5; the small launches' own inverse transform: twice the workgroups of k_ntt15_p1<true, 0>,
+// half the serial chain each), in place.  grid (16 column tiles, X * nsl limb-polynomials)
+__global__ __launch_bounds__(256) void k_ntt15_p1inv8(NttTables T, u64 *__restrict__ dst, size_t dso, LimbSel sel, int slot0, int nsl, ScaleSel scale) {
+    constexpr int N = 32768;
+    __shared__ u64 lds[CF8_IMG];
+    __shared__ ulonglong2 ltw[128];
+    const int y = blockIdx.y, x = y / nsl, slot = slot0 + (y - x * nsl), m = sel.mod[slot];
+    const ModC M = T.mod[m];
+    const bool fp = (T.fp_mask >> m) & 1u;
+    const ulonglong2 *__restrict__ tw = (fp ? T.itwf : T.itwp) + (size_t)m * N;
+    const int t = threadIdx.x, col = t & (CF8_COLS - 1), g = t >> 4;
+    u64 *d = dst + (size_t)x * dso + (size_t)slot * N + blockIdx.x * CF8_COLS + col;
+    u64 yv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) yv[k] = d[(size_t)(8 * g + k) * 256];  // raw from pass 2'
+    if (t < 128) ltw[t] = tw[t];
+    __syncthreads();
+    if (fp) cf_inverse8<FpA>(FpA(M), tw, ltw, lds, g, col, scale.s[slot], scale.s_sh[slot], yv);
+    else if ((T.pm_mask >> m) & 1u) cf_inverse8<IntP>(IntP(M), tw, ltw, lds, g, col, scale.s[slot], scale.s_sh[slot], yv);
+    else cf_inverse8<IntA>(IntA(M), tw, ltw, lds, g, col, scale.s[slot], scale.s_sh[slot], yv);
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[(size_t)(g + 16 * k) * 256] = yv[k];
+}
+
 }  // namespace
 
 namespace hk {
@@ -728,6 +843,13 @@ namespace hk {
 // launches below 256 32-column tiles take the small-launch form (pass 1' as its own launch + one target per workgroup; the crossover was
 // re-measured with the narrow kernel in round 5: nothing between 0 and 256 tiles leaves the run-to-run spread)
 bool ntt15_colfuse_small(int XP, int ncf) { return 8 * XP * ncf < 256; }
+// inverse pass 1' of a SMALL launch (fewer than 1024 of the 32-column workgroups) on 16-column tiles; false: the caller launches k_ntt15_p1<true, 0>
+bool ntt15_inverse_p1_narrow(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl, const ScaleSel &scale) {
+    if (T.cf_wide || 8 * X * nsl >= 1024) return false;
+    ledger_add("k_ntt15_p1inv8", 2.0 * X * nsl * 262144.0);
+    hipLaunchKernelGGL(k_ntt15_p1inv8, dim3(16, X * nsl), dim3(256), 0, st, T, dst, dso, sel, slot0, nsl, scale);
+    return true;
+}
 
 void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
                    const ColFuse *h_cf, int ncf, bool pre) {
@@ -746,7 +868,13 @@ void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so
         nt_max = std::max(nt_max, h_cf[i].nt);
         rows += h_cf[i].nk + (h_cf[i].mdr ? 1 : 0) + h_cf[i].nt;
     }
-    if (pre) {  // small launch: one target per workgroup, the light kernel
+    if (pre && !T.cf_wide) {  // small launch: one target per workgroup, 16-column tiles
+        ledger_add(mdr ? "k_ntt15_conv_p1_8<true>" : "k_ntt15_conv_p1_8<false>", rows * XP * 262144.0);
+        if (mdr) hipLaunchKernelGGL((k_ntt15_conv_p1_8<true>), dim3(16, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
+        else hipLaunchKernelGGL((k_ntt15_conv_p1_8<false>), dim3(16, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
+        return;
+    }
+    if (pre) {  // ... on round 4's 32-column tiles
         ledger_add(mdr ? "k_ntt15_conv_p1<true>" : "k_ntt15_conv_p1<false>", rows * XP * 262144.0);
         if (mdr) hipLaunchKernelGGL((k_ntt15_conv_p1<true>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);
         else hipLaunchKernelGGL((k_ntt15_conv_p1<false>), dim3(8, XP, ncf * nt_max), dim3(256), 0, st, T, src, so, dst, dso, d_cf, nt_max);

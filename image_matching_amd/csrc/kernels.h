@@ -357,6 +357,9 @@ void ntt15_forward_p2_fused(hipStream_t st, const NttTables &T, u64 *dst, size_t
 void ntt15_colfuse(hipStream_t st, const NttTables &T, const u64 *src, size_t so, u64 *dst, size_t dso, int XP, const ColFuse *d_cf,
                    const ColFuse *h_cf, int ncf, bool pre = false);
 bool ntt15_colfuse_small(int XP, int ncf);
+// inverse pass 1' of a small launch on 16-column tiles (colfuse.hip k_ntt15_p1inv8), in place on dst; returns false when the launch is large
+// (or HYDIA_COLFUSE_WIDE): the caller then launches the 32-column kernel
+bool ntt15_inverse_p1_narrow(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, int slot0, int nsl, const ScaleSel &scale);
 // out[x][p][j][c'] = ((acc[x][p][j][c] - conv[x][p][j][c]) * pinv[j] + (addend ? addend[x*add_x + p*add_ps + j*N + c] : 0)),
 // c = perm_g(c') when galois[x] != 1 (evaluation-form automorphism), acc rows have stride acc_limbs*N
 void moddown_combine(hipStream_t st, const ModC *mod, int logN, const u64 *acc, int acc_limbs, const u64 *conv,

@@ -1743,6 +1743,7 @@ void ntt15_inverse_p2_last_limb(hipStream_t st, const NttTables &T, const u64 *a
 }
 void ntt15_inverse_p1(hipStream_t st, const NttTables &T, u64 *dst, size_t dso, int X, const LimbSel &sel, const ScaleSel &scale) {
     NttLoad ld{};
+    if (ntt15_inverse_p1_narrow(st, T, dst, dso, X, sel, 0, sel.n, scale)) return;
     ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * sel.n * 262144.0);
     hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * sel.n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, 0, sel.n, scale, ld);
 }
@@ -1757,7 +1758,6 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
             return;
         }
         ledger_add(pair_polys(X, n) ? "k_ntt15_p2<true, 2, 0>" : "k_ntt15_p2<true, 1, 0>", 2.0 * X * n * 262144.0);
-        ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * n * 262144.0);
         if (T.p2_wg_sync) {
             if (pair_polys(X, n))
                 hipLaunchKernelGGL((k_ntt15_p2_wgsync<true, 2>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
@@ -1767,6 +1767,8 @@ void ntt15_inverse(hipStream_t st, const NttTables &T, const u64 *src, u64 *dst,
             hipLaunchKernelGGL((k_ntt15_p2<true, 2, 0>), dim3(16, (X / 2) * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
         else
             hipLaunchKernelGGL((k_ntt15_p2<true, 1, 0>), dim3(16, X * n), dim3(256), 0, st, T, src, dst, so, dso, sel, s0, n, stp);
+        if (ntt15_inverse_p1_narrow(st, T, dst, dso, X, sel, s0, n, scale)) return;  // small launch: 16-column tiles
+        ledger_add("k_ntt15_p1<true, 0>", 2.0 * X * n * 262144.0);
         hipLaunchKernelGGL((k_ntt15_p1<true, 0>), dim3(8, X * n), dim3(256), 0, st, T, dst, dst, dso, dso, sel, s0, n, scale, ld);
     });
 }
