@@ -20,11 +20,11 @@ sys.path.insert(0, ROOT)
 import image_matching_amd as im  # noqa: E402
 
 
-def fp64_chain(count=4):
+def fp64_chain(count=4, bits=47):
     d, mod, _ = im.describe_params(im.default_params())
     nq = d["n_q"]
     M = 2 << 15
-    c = (1 << 47) - ((1 << 47) % M) + 1
+    c = (1 << bits) - ((1 << bits) % M) + 1
     p = []
     while len(p) < count:
         c -= M
@@ -81,6 +81,12 @@ def main():
         cc.close()
         cc = im.Context(im.default_params(), 0, moduli=moduli, n_p=5)
         print("five 47-bit special primes, dnum 3: 2^%d: %.3f ms per query" % (L, timed(cc, 1 << L, Q)), flush=True)
+        cc.close()
+        return
+    if len(sys.argv) > 3 and sys.argv[3] == "6x41":  # SIX special primes (246 bits): outside the fused pipeline (cf_ok() false) — the unfused kernels must serve it
+        moduli, nq = fp64_chain(6, 41)
+        cc = im.Context(im.default_params(), 0, moduli=moduli, n_p=6)
+        print("six 41-bit special primes, dnum 3 (unfused pipeline): check at 2^14:", check(cc), flush=True)
         cc.close()
         return
     moduli, nq = fp64_chain()
