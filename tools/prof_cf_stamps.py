@@ -26,21 +26,28 @@ gq = cc.import_ct(q, cc.delta)
 snd = im.DiagonalSender(cc, n)
 r = snd.indexScenario(gq)
 cc.sync()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 lib.hydia_debug_cf_stamps(None, 1)
 r = snd.indexScenario(gq)
 cc.sync()
 lib.hydia_debug_cf_stamps(buf, 0)
-v = list(buf)
-wgs, tgts = v[15], v[14]
-names = {0: "before the target loop (source loads, inverse transforms, dropped-limb correction), per workgroup",
+allv = list(buf)
+PRO = bool(os.environ.get("CF_STAMPS_PROLOGUE"))  # the second diagnostic build: the prologue cut finer (sections 0-5), the whole target loop as one
+names = {0: "kernel entry -> table rows arrived, staging stores issued", 1: "first barrier", 2: "wait until every source load has arrived",
+         3: "the inverse transforms (paired)", 4: "dropped-limb correction (+ barrier)", 5: "the target loop", 6: "-", 7: "-"} if PRO else {
+         0: "before the target loop (source loads, inverse transforms, dropped-limb correction)",
          1: "conversion of an FP64 target (+ wait for its twiddle row, + the previous target's store tail)", 7: "conversion of a 60-bit target (same)",
          2: "phase A butterflies + exchange write", 3: "barrier 1", 4: "phase B (exchange read, butterflies, exchange write)", 5: "barrier 2",
          6: "phase C + the 8 global stores"}
-tot = sum(v[i] for i in range(8))
-print("one 2^%d indexScenario, every launch of k_ntt15_colfuse8: %d workgroups, %d targets (%.1f per workgroup); wave 0's cycle counter (100 MHz ticks x? see note)" % (L, wgs, tgts, tgts / max(wgs, 1)))
-for i in (0, 1, 7, 2, 3, 4, 5, 6):
-    print("  %5.1f %%  %12d ticks  %s" % (100.0 * v[i] / tot, v[i], names[i]))
-print("  ticks per workgroup: %.0f; per target iteration (sections 1-7 / targets): %.0f" % (tot / wgs, (tot - v[0]) / max(tgts, 1)))
+order = (0, 1, 2, 3, 4, 5) if PRO else (0, 1, 7, 2, 3, 4, 5, 6)
+for kind, o in (("k_ntt15_colfuse8<false> (ModUp digits, loop A's ModDown)", 0), ("k_ntt15_colfuse8<true> (merged ModDown + Rescale, Rescale)", 16)):
+    v = allv[o:o + 16]
+    wgs, tgts = v[15], v[14]
+    if not wgs:
+        continue
+    tot = sum(v[i] for i in range(8))
+    print("%s: %d workgroups, %.1f targets each, %.0f cycles per workgroup, %.0f per target iteration" % (kind, wgs, tgts / wgs, tot / wgs, (tot - v[0]) / max(tgts, 1)))
+    for i in order:
+        print("  %5.1f %%  %8.0f cycles per workgroup  %s" % (100.0 * v[i] / tot, v[i] / wgs, names[i]))
 del r, gq, snd
 cc.close()
