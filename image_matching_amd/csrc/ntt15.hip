@@ -874,18 +874,45 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                 for (int p = 0; p < NP; p++) pre[hh][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem<WGS>(t, hh)), M);
             if (ST == 9 || ST == 10 || ST == 11) po.load(stp.prod, xp0 >> 1, slot, (unsigned)(B0 + p2_elem<WGS>(t, 0)));
         }
+        // mode 4 / 6: the key rows of the inner product
+        const u64 *const ip_key = (ST == 4 || ST == 6) ? (stp.ip.keys ? stp.ip.keys[xp0] : stp.ip.key) : nullptr;  // one key, or one per ciphertext
+        const int ip_t = slot, ip_m = ip_t < stp.ip.nl ? ip_t : stp.ip.nT - stp.ip.nE + ip_t;
+        const int ip_own = (stp.ip.own && ip_t < stp.ip.nl) ? ip_t / stp.ip.alpha : (1 << 30);
+        // Round 5 (in-kernel section timing, profiles/r05/ip_stamps.txt): an FP64 row of the fused inner product spent 84 % of its time in phase C,
+        // whose vector work is a fifth of that — the group's twiddles and each digit's key residues were requested one after the other, each
+        // where it is used, and every request waited out a full L2 / Infinity-Cache round trip.  The FP64 path has the registers the 60-bit path
+        // sets the kernel's budget with, so it requests a group's twiddles and EVERY digit's key residues in one batch — the first group's before
+        // the last exchange, the second group's at the top of its iteration.
+        constexpr bool KB = (ST == 4 || ST == 6) && std::is_same<A, FpA>::value && !WGS;
+        ulonglong2 kq[KB ? NP : 1][4];
+        TW Wq[3];
+        auto ip_request = [&](int hh) {
+            const int e = p2_elem<WGS>(t, hh), gi = (B0 + e) >> 2;
+            Wq[0] = A::tw(tw[8192 + gi]);
+            Wq[1] = A::tw(tw[16384 + 2 * gi]);
+            Wq[2] = A::tw(tw[16384 + 2 * gi + 1]);
+#pragma unroll
+            for (int p = 0; p < (KB ? NP : 1); p++) {
+                const int dgt = p >= ip_own ? p + 1 : p;
+                const u64 *kb = ip_key + (((size_t)dgt * 2) * stp.ip.nT + ip_m) * 32768 + (B0 + e);
+                const u64 *ka = kb + (size_t)stp.ip.nT * 32768;
+                kq[p][0] = *reinterpret_cast<const ulonglong2 *>(kb);
+                kq[p][1] = *reinterpret_cast<const ulonglong2 *>(kb + 2);
+                kq[p][2] = *reinterpret_cast<const ulonglong2 *>(ka);
+                kq[p][3] = *reinterpret_cast<const ulonglong2 *>(ka + 2);
+            }
+        };
+        if (KB) ip_request(0);
         p2_sync<WGS>();
         // phase C: two groups of 4 consecutive coefficients e = 4t + 1024*hh ; stages 13, 14 (strides 2, 1)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int e = p2_elem<WGS>(t, hh), u = e & 255, la = LI::at(e >> 8, u >> 5, u & 31);  // four consecutive slots (u & 31 is a multiple of 4)
             const int gi = (B0 + e) >> 2;
-            const TW W13 = A::tw(tw[8192 + gi]), W14a = A::tw(tw[16384 + 2 * gi]), W14b = A::tw(tw[16384 + 2 * gi + 1]);
+            if (KB && hh == 1) ip_request(1);
+            const TW W13 = KB ? Wq[0] : A::tw(tw[8192 + gi]), W14a = KB ? Wq[1] : A::tw(tw[16384 + 2 * gi]), W14b = KB ? Wq[2] : A::tw(tw[16384 + 2 * gi + 1]);
             // mode 4: lazy 128-bit sums of value * key over the digits this workgroup transforms (+ the limb's own digit)
             IpAcc<A> ipb[4], ipa[4];
-            const u64 *const ip_key = (ST == 4 || ST == 6) ? (stp.ip.keys ? stp.ip.keys[xp0] : stp.ip.key) : nullptr;  // one key, or one per ciphertext
-            const int ip_t = slot, ip_m = ip_t < stp.ip.nl ? ip_t : stp.ip.nT - stp.ip.nE + ip_t;
-            const int ip_own = (stp.ip.own && ip_t < stp.ip.nl) ? ip_t / stp.ip.alpha : (1 << 30);
             if (SPLIT && hh == 1) {
 #pragma unroll
                 for (int p = 0; p < NP; p++) pre[0][p] = p2_prefetch<ST>(stp, ar, xp0 + p, slot, (unsigned)(B0 + p2_elem<WGS>(t, 1)), M);
@@ -905,8 +932,8 @@ DEV void p2_body(const A ar, const ulonglong2 *__restrict__ tw, const u64 *const
                     const int dgt = p >= ip_own ? p + 1 : p;
                     const u64 *kb = ip_key + (((size_t)dgt * 2) * stp.ip.nT + ip_m) * 32768 + (B0 + e);
                     const u64 *ka = kb + (size_t)stp.ip.nT * 32768;
-                    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(kb), b1 = *reinterpret_cast<const ulonglong2 *>(kb + 2);
-                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(ka), a1 = *reinterpret_cast<const ulonglong2 *>(ka + 2);
+                    const ulonglong2 b0 = KB ? kq[KB ? p : 0][0] : *reinterpret_cast<const ulonglong2 *>(kb), b1 = KB ? kq[KB ? p : 0][1] : *reinterpret_cast<const ulonglong2 *>(kb + 2);
+                    const ulonglong2 a0 = KB ? kq[KB ? p : 0][2] : *reinterpret_cast<const ulonglong2 *>(ka), a1 = KB ? kq[KB ? p : 0][3] : *reinterpret_cast<const ulonglong2 *>(ka + 2);
                     ipb[0].mac(ar, vv[0], b0.x); ipb[1].mac(ar, vv[1], b0.y); ipb[2].mac(ar, vv[2], b1.x); ipb[3].mac(ar, vv[3], b1.y);
                     ipa[0].mac(ar, vv[0], a0.x); ipa[1].mac(ar, vv[1], a0.y); ipa[2].mac(ar, vv[2], a1.x); ipa[3].mac(ar, vv[3], a1.y);
                 } else if (ST == 0) {
