@@ -247,7 +247,7 @@ def test_five_special_primes_below_2p48_full_ring(im):
     for i in planted:
         db[i] = rng.integers(1, 4, size=512)
     query = np.ones(512)
-    for matvec in ("hoisted", None):  # the reference's form (511 hoisted rotations: loop A's five-source ModDown) and the auto split
+    for matvec in ("hoisted",):  # the reference's form: 511 hoisted rotations (loop A's five-source ModDown), one relinearisation (five-source merged ModDown + Rescale)
         dbc = Or.enroll(db.copy(), 8, **({"matvec": matvec} if matvec else {}))
         cc.set_matvec(matvec or "auto")
         im.DiagonalEnroller(cc, n).serializeDB(db.copy(), seed=8)
